@@ -1,0 +1,473 @@
+"""Generate golden input/output vectors by running the REAL reference
+(``/root/reference``, vanilladucky/sde_sampler_lrds) in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+Only this script touches the reference; the resulting ``*.npz`` fixtures are data
+(inputs + expected outputs) and are what travels to the GPU box.
+
+How the reference is brought up: ``wandb``, ``torchquad`` and
+``torchsde`` are imported by reference modules but never used on this path, and are not
+installed here, so empty stand-in modules are registered for those three names.
+``sde_sampler.solver.*`` needs hydra/omegaconf (absent) and is not imported: each solver
+is assembled by hand exactly as its ``setup_models`` does (solver/oc.py:43-78, 358-378,
+438-452, 273-289, 499-511) with the constants of ``conf/``.
+
+Noise: the reference draws one ``torch.randn_like(x)`` per step.  While a case runs,
+``torch.randn_like`` is replaced by a replay of the engine's counter-based noise
+definition (``oracle.sde_oracle.philox_normal(seed, step, ...)``), so a fixture only has to
+store the seed, and every implementation consumes bit-identical normals.
+
+``data/sonar.pkl`` is a pickle and ``torch.load(weights_only=True)`` refuses it, so it is
+NOT loaded: the logistic-regression case uses a synthetic design matrix of the same shape
+and value range (X [166,60] in [1e-4,1], y in {0,1}) and the reference's
+``LogisticRegression`` arithmetic methods on it (the constructor, which unpickles, is bypassed).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+for _n in ("wandb", "torchquad", "torchsde"):
+    sys.modules.setdefault(_n, types.ModuleType(_n))
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import sde_oracle as orc  # noqa: E402  (only for the noise definition)
+
+from sde_sampler.distr import base as r_base  # noqa: E402
+from sde_sampler.distr import delta as r_delta  # noqa: E402
+from sde_sampler.distr import gauss as r_gauss  # noqa: E402
+from sde_sampler.distr import logistic_regression as r_lr  # noqa: E402
+from sde_sampler.distr import phi_four as r_phi  # noqa: E402
+from sde_sampler.distr import rings as r_rings  # noqa: E402
+from sde_sampler.eq import sdes as r_sdes  # noqa: E402
+from sde_sampler.losses import oc as r_oc  # noqa: E402
+from sde_sampler.models import mlp as r_mlp  # noqa: E402
+from sde_sampler.models import reparam as r_rep  # noqa: E402
+from sde_sampler.models import utils as r_mu  # noqa: E402
+from sde_sampler.utils.common import get_timesteps as r_get_timesteps  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- helpers
+class Replay:
+    """Stand-in for torch.randn_like during a reference run: step k -> philox_normal(seed, k)."""
+
+    def __init__(self, seed):
+        self.seed, self.k = seed, 0
+
+    def __call__(self, x, *a, **kw):
+        z = orc.philox_normal(self.seed, self.k, 0, x.shape[0], x.shape[1])
+        self.k += 1
+        return z
+
+
+def run_with_replay(seed, fn):
+    orig = torch.randn_like
+    rep = Replay(seed)
+    torch.randn_like = rep
+    try:
+        with torch.no_grad():
+            out = fn()
+    finally:
+        torch.randn_like = orig
+    return out, rep.k
+
+
+def fourier_mlp(dim):
+    return r_mlp.FourierMLP(dim=dim, activation=torch.nn.GELU(), num_layers=4, channels=64,
+                            last_bias_init=r_mu.init_bias_uniform_zeros,
+                            last_weight_init=r_mu.kaiming_uniform_zeros_)
+
+
+def score_time_embed(bias=0.0):
+    m = r_mlp.TimeEmbed(dim_out=1, activation=torch.nn.GELU(), num_layers=4, channels=64,
+                        last_bias_init=r_mu.init_bias_uniform_zeros,
+                        last_weight_init=r_mu.kaiming_uniform_zeros_)
+    with torch.no_grad():
+        m.out_layer.weight.uniform_(-0.02, 0.02)
+        m.out_layer.bias.fill_(bias)
+    return m
+
+
+def liven(net, scale=0.1):
+    """The reference initialises the last layer at ~1e-6 so the net is a no-op at init;
+    re-randomise it so that the drift net matters in the fixture."""
+    with torch.no_grad():
+        net.out_layer.weight.uniform_(-scale, scale)
+        net.out_layer.bias.uniform_(-scale, scale)
+    return net
+
+
+def sd(module):
+    return {k: v.detach().clone().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name, meta, arrays):
+    path = os.path.join(HERE, name + ".npz")
+    arrays = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
+    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KB  logZ={meta.get('log_norm_const_is')}")
+
+
+def finish(name, meta, arrays, res, nsteps_drawn):
+    meta = dict(meta)
+    meta["log_norm_const_is"] = res.log_norm_const_preds["log_norm_const_is"]
+    meta["elbo"] = res.metrics["eval/elbo"]
+    meta["lv_loss"] = res.metrics["eval/lv_loss"]
+    meta["draws"] = nsteps_drawn
+    arrays = dict(arrays)
+    arrays["out_x"] = res.samples
+    arrays["out_weights"] = res.weights
+    save(name, meta, arrays)
+
+
+def pack_params(prefix, state):
+    return {f"{prefix}{k}": v for k, v in state.items()}
+
+
+# ----------------------------------------------------------------------------- cases
+def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", beta_max=10.0, t_end=None):
+    """RDS with a diagonal-GMM reference (solver/oc.py:563-576), VP noising, basic model
+    (conf/solver/vp_rds.yaml, conf/model/basic.yaml)."""
+    torch.manual_seed(seed)
+    sde = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=beta_max, scale_diff_coeff=1.0, terminal_t=1.0)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0,
+                               n_reference_samples=10)
+    ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
+    means = target.loc.clone() + 0.1 * torch.randn(K, d)
+    variances = 0.5 * torch.ones(K, d) * (1.0 + 0.2 * torch.rand(K, d))
+    weights = torch.ones(K)
+    ref_utils = dict(means_init=means, variances_init=variances, weights_init=weights)
+    ref_distr = sde.marginal_gmm_distr(t=torch.tensor(0.0), **ref_utils)
+    ref_ctrl = lambda t, x: sde.marginal_gmm_score(t=t, x=x, **ref_utils)  # noqa: E731
+    cls = {"ei": r_oc.EIReferenceSDELoss, "ddpm_like": r_oc.DDPMLikeReferenceSDELoss,
+           "em": r_oc.EMReferenceSDELoss}[integrator]
+    loss = cls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref_ctrl)
+    if time_type == "snr":
+        ts = r_get_timesteps(1e-4, 1.0 - 1e-4, steps=N, sde=sde)
+    else:
+        ts = r_get_timesteps(0.0, 1.0 if t_end is None else t_end, steps=N)
+    x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)  # IsotropicGauss prior, scale 1
+    res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob,
+                                                         compute_weights=True, return_traj=True, use_ema=False))
+    # step-0 intermediates
+    with torch.no_grad():
+        T = ts[-1]
+        u0 = ctrl(T - ts[0], x0)
+        r0 = ref_ctrl(T - ts[0], x0)
+    with torch.no_grad():
+        (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
+            ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=ref_distr.log_prob))
+    meta = dict(kind="rds_gmm", integrator=integrator, d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=beta_max,
+                sigma=1.0, T=1.0, clip_model=1e4, time_type=time_type)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], u0=u0, ref0=r0,
+                  tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights,
+                  ref_means=means, ref_vars=variances, ref_w=weights, **pack_params("ctrl.", sd(ctrl)))
+    finish(name, meta, arrays, res, draws)
+
+
+def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em"):
+    """RDS with the default Gaussian reference (solver/oc.py:535-551): VP + IsotropicGauss prior, or
+    PinnedBM + Delta prior (conf/solver/vp_rds.yaml, pbm_rds.yaml)."""
+    torch.manual_seed(seed)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
+    ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
+    if sde_kind == "vp":
+        sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
+        x_init, var_init = torch.zeros(d), torch.ones(d)
+        ts = r_get_timesteps(0.0, 1.0, steps=N)
+        x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
+        sde_meta = dict(sde="vp", beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0)
+    else:
+        g, T = math.sqrt(0.2), 5.0
+        sde = r_sdes.PinnedBM(diff_coeff=g, terminal_t=T)
+        x_init = torch.zeros(d)
+        var_init = sde.terminal_t * sde.diff_coeff ** 2 * torch.ones(d)
+        ts = r_get_timesteps(1e-4, T - 1e-4, steps=N, sde=sde)
+        x0 = torch.zeros(B, d)
+        sde_meta = dict(sde="pbm", diff_coeff=g, T=T)
+    ref_distr = sde.marginal_distr(t=torch.tensor(0.0), x_init=x_init, var_init=var_init)
+    ref_ctrl = lambda t, x: sde.marginal_score(t=t, x=x, x_init=x_init, var_init=var_init)  # noqa: E731
+    cls = {"ei": r_oc.EIReferenceSDELoss, "ddpm_like": r_oc.DDPMLikeReferenceSDELoss,
+           "em": r_oc.EMReferenceSDELoss}[integrator]
+    loss = cls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref_ctrl)
+    res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob,
+                                                         compute_weights=True, return_traj=True, use_ema=False))
+    (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
+        ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=ref_distr.log_prob))
+    meta = dict(kind="rds_default", integrator=integrator, d=d, K=K, B=B, N=N, seed=seed, clip_model=1e4, **sde_meta)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], tgt_loc=target.loc, tgt_scale=target.scale,
+                  tgt_w=target.mixture_weights, ref_x_init=x_init, ref_var_init=var_init,
+                  **pack_params("ctrl.", sd(ctrl)))
+    finish(name, meta, arrays, res, draws)
+
+
+def case_pis_phi4(name, d, B, N, seed, dt):
+    """PIS on PhiFour (conf/solver/pis.yaml, conf/model/score.yaml, conf/target/phi_four.yaml,
+    solver/oc.py:358-378): ScaledBM(sqrt .2, T=5), Delta prior, ScoreCtrl."""
+    torch.manual_seed(seed)
+    g, Tstar = math.sqrt(0.2), 5.0
+    sde = r_sdes.ScaledBM(diff_coeff=g, terminal_t=Tstar)
+    target = r_phi.PhiFour(a=0.1, b=0.0, dim=d, dim_phys=1, beta=20.0)
+    prior = r_delta.Delta(dim=d)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.02),
+                           target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                           scale_score=1.0)
+    ref_distr = sde.marginal_distr(t=sde.terminal_t, x_init=prior.loc)
+    loss = r_oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    ts = torch.linspace(0.0, N * dt, N + 1)
+    x0 = prior.sample((B,))
+    res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob,
+                                                         compute_weights=True, return_traj=True, use_ema=False))
+    (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
+        ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=ref_distr.log_prob))
+    with torch.no_grad():
+        xm = res.xs[N // 2]
+        u_mid = ctrl(ts[-1] - ts[N // 2], xm)
+    meta = dict(kind="pis_phi4", d=d, B=B, N=N, seed=seed, diff_coeff=g, T=Tstar, a=0.1, b=0.0, beta=20.0,
+                clip_model=1e4, clip_score=1e4, scale_score=1.0)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], x_mid=xm, u_mid=u_mid,
+                  ref_loc=ref_distr.loc, ref_scale=ref_distr.scale, **pack_params("ctrl.", sd(ctrl)))
+    finish(name, meta, arrays, res, draws)
+
+
+def case_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0):
+    """DDS on TwoModes (conf/solver/dds.yaml, conf/loss/exponential_sde.yaml, solver/oc.py:438-452)."""
+    torch.manual_seed(seed)
+    target = r_gauss.TwoModes(dim=d, a=1.0, ill_conditioned="not", n_reference_samples=10)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=sigma)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.01),
+                           target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                           scale_score=1.0)
+    loss = r_oc.ExponentialIntegratorSDELoss(ctrl, ctrl, sde=None, method="kl", alpha=1.0, sigma=sigma)
+    ts = r_get_timesteps(0.0, end, dt=dt, rescale_t="cosine")
+    x0 = sigma * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, prior.log_prob,
+                                                         compute_weights=True, return_traj=True, use_ema=False))
+    (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
+        ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=prior.log_prob,
+        compute_ito_int=True))
+    meta = dict(kind="dds", d=d, B=B, N=len(ts) - 1, seed=seed, alpha=1.0, sigma=sigma, clip_model=1e4, clip_score=1e4,
+                scale_score=1.0, dt=dt, end=end)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], tgt_loc=target.loc, tgt_scale=target.scale,
+                  tgt_w=target.mixture_weights, **pack_params("ctrl.", sd(ctrl)))
+    finish(name, meta, arrays, res, draws)
+
+
+class SyntheticLogReg(r_lr.LogisticRegression):
+    """The reference's LogisticRegression with its file-reading constructor bypassed
+    (distr/logistic_regression.py:14-39 restated for in-memory data); every arithmetic
+    method (posterior_log_prob, the autograd score of distr/base.py:146-154) is the reference's own."""
+
+    def __init__(self, X, y, intercept_mean, intercept_scale, weight_scale):
+        r_base.Distribution.__init__(self, dim=X.shape[1] + 1)
+        self.X_train, self.y_train = X.float(), y.float().flatten()
+        self.X_test, self.y_test = self.X_train, self.y_train
+        dw = X.shape[1]
+        self.threshold = 1e-8
+        self.register_buffer("weight_scale", torch.tensor(weight_scale), persistent=False)
+        self.weights_prior = torch.distributions.Independent(
+            torch.distributions.Normal(loc=torch.zeros((dw,)), scale=self.weight_scale * torch.ones((dw,))), 1)
+        self.use_intercept = True
+        self.register_buffer("intercept_mean", torch.tensor(intercept_mean), persistent=False)
+        self.register_buffer("intercept_scale", torch.tensor(intercept_scale), persistent=False)
+        self.intercept_prior = torch.distributions.Normal(loc=self.intercept_mean, scale=self.intercept_scale)
+
+
+def synthetic_sonar(seed=7):
+    g = torch.Generator().manual_seed(seed)
+    X = (1e-4 + (1 - 1e-4) * torch.rand(166, 60, generator=g) ** 2).float()
+    y = (torch.rand(166, generator=g) < 0.47).float()
+    return X, y
+
+
+def case_cmcd_logreg(name, B, N, seed, dt):
+    """CMCD on (synthetic-)sonar logistic regression (conf/solver/cmcd.yaml, conf/target/sonar.yaml,
+    solver/oc.py:273-303): ControlledLangevinSDE(g=1, T=1, clip 1e5), GaussFull prior, ScoreCtrl."""
+    torch.manual_seed(seed)
+    X, y = synthetic_sonar()
+    target = SyntheticLogReg(X, y, intercept_mean=-2.5, intercept_scale=0.5, weight_scale=4.5)
+    d = target.dim
+    A = torch.randn(d, d)
+    cov = 0.01 * A @ A.T + 0.5 * torch.eye(d)
+    mean = 0.1 * torch.randn(d)
+    prior = r_gauss.GaussFull(dim=d, loc=mean, cov=cov)
+    sde = r_sdes.ControlledLangevinSDE(target_score=target.score, prior_score=prior.score, diff_coeff=1.0,
+                                       terminal_t=1.0, clip_score=1e5)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.01),
+                           target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                           scale_score=1.0)
+    loss = r_oc.ControlledLangevinSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    ts = torch.linspace(0.0, N * dt, N + 1)
+    L = torch.linalg.cholesky(cov)
+    x0 = mean + orc.philox_normal(seed, 0, 0, B, d, stream=1) @ L.T
+
+    def ev():
+        return loss.eval(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob,
+                         compute_weights=True, return_traj=True, use_ema=False)
+
+    # Distribution.score needs autograd, so this case runs without the no_grad wrapper of run_with_replay
+    orig = torch.randn_like
+    rep = Replay(seed)
+    torch.randn_like = rep
+    try:
+        res = ev()
+        draws = rep.k
+        rep.k = 0
+        x_n, rnd, _ = loss.simulate(ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob,
+                                    initial_log_prob=prior.log_prob, train=False)
+    finally:
+        torch.randn_like = orig
+    xq = torch.cat([x0[:16], 5.0 * x0[:8], 30.0 * x0[:8]])
+    sc = target.score(xq.clone())
+    lp = target.unnorm_log_prob(xq).detach()
+    meta = dict(kind="cmcd_logreg", d=d, B=B, N=N, seed=seed, diff_coeff=1.0, T=1.0, clip_langevin=1e5, clip_model=1e4,
+                clip_score=1e4, scale_score=1.0, intercept_mean=-2.5, intercept_scale=0.5, weight_scale=4.5,
+                data="synthetic sonar-shaped (sonar.pkl not loadable with a safe loader)")
+    arrays = dict(ts=ts, x0=x0, rnd=rnd.detach(), xs_last2=res.xs[-2:].detach(), X=X, y=y, prior_loc=mean,
+                  prior_cov=cov, score_x=xq, score_out=sc.detach(), logp_out=lp,
+                  prior_logp_x0=prior.log_prob(x0).detach(), prior_score_x0=prior.score(x0).detach(),
+                  **pack_params("ctrl.", sd(ctrl)))
+    res = res._replace(samples=res.samples.detach(), weights=res.weights.detach())
+    finish(name, meta, arrays, res, draws)
+
+
+def case_dis(name, d, K, B, N, seed, kind):
+    """DIS: kind='ei' -> DiscreteTimeReversalLossEI with ScoreCtrl; kind='orig' -> TimeReversalLoss with
+    LerpCtrl (conf/solver/dis.yaml, conf/model/lerp.yaml, solver/oc.py:185-261)."""
+    torch.manual_seed(seed)
+    sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=1.0)
+    if kind == "ei":
+        ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.2),
+                               target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                               scale_score=1.0)
+        loss = r_oc.DiscreteTimeReversalLossEI(ctrl, ctrl, sde=sde, method="kl")
+    else:
+        ctrl = r_rep.LerpCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0),
+                              target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                              scale_score=1.0, sde=sde, prior_score=prior.score)
+        loss = r_oc.TimeReversalLoss(ctrl, ctrl, sde=sde, method="kl", inference_ctrl=None)
+    ts = r_get_timesteps(0.0, 1.0, steps=N)
+    x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob,
+                                                         initial_log_prob=prior.log_prob, compute_weights=True,
+                                                         return_traj=True, use_ema=False))
+    kw = dict(train=False) if kind == "ei" else dict(train=False, compute_ito_int=True)
+    (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
+        ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, initial_log_prob=prior.log_prob, **kw))
+    meta = dict(kind="dis_" + kind, d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0,
+                clip_model=1e4, clip_score=1e4, scale_score=1.0)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], tgt_loc=target.loc, tgt_scale=target.scale,
+                  tgt_w=target.mixture_weights, **pack_params("ctrl.", sd(ctrl)))
+    finish(name, meta, arrays, res, draws)
+
+
+def unit_vectors():
+    """Isolated known-answer vectors: scores / log-probs / SDE scalars / time grids / net forward."""
+    torch.manual_seed(123)
+    out, meta = {}, {}
+    # GMM score + log-prob (distr/gauss.py:97-107, 217-221)
+    tgt = r_gauss.ManyModes(n_modes=5, dim=12, var=0.5, n_reference_samples=10)
+    x = 3.0 * torch.randn(40, 12)
+    out.update(gmm_loc=tgt.loc, gmm_scale=tgt.scale, gmm_w=tgt.mixture_weights.clone(), gmm_x=x,
+               gmm_score=tgt.score(x.clone()), gmm_logp=tgt.unnorm_log_prob(x))
+    # PhiFour (distr/phi_four.py:54-96)
+    phi = r_phi.PhiFour(a=0.1, b=0.3, dim=20, beta=20.0)
+    xp = 0.8 * torch.randn(16, 20)
+    out.update(phi_x=xp, phi_score=phi.score(xp), phi_logp=phi.unnorm_log_prob(xp))
+    meta["phi"] = dict(a=0.1, b=0.3, dim=20, beta=20.0)
+    # Rings (distr/rings.py:93-109)
+    rg = r_rings.Rings()
+    xr = 3.0 * torch.randn(32, 2)
+    out.update(rings_x=xr, rings_score=rg.score(xr), rings_logp=rg.unnorm_log_prob(xr))
+    # IsotropicGauss / Gauss / GaussFull
+    iso = r_gauss.IsotropicGauss(dim=12, loc=0.5, scale=1.7)
+    out.update(iso_logp=iso.log_prob(x), iso_score=iso.score(x))
+    meta["iso"] = dict(dim=12, loc=0.5, scale=1.7)
+    gd = r_gauss.Gauss(dim=12, loc=torch.linspace(-1, 1, 12), scale=torch.linspace(0.5, 2.0, 12))
+    out.update(gd_loc=gd.loc, gd_scale=gd.scale, gd_logp=gd.log_prob(x), gd_score=gd.score(x))
+    A = torch.randn(12, 12)
+    cov = 0.1 * A @ A.T + 0.5 * torch.eye(12)
+    gf = r_gauss.GaussFull(dim=12, loc=torch.linspace(-1, 1, 12), cov=cov)
+    out.update(gf_loc=gf.loc, gf_cov=cov, gf_logp=gf.log_prob(x), gf_score=gf.score(x))
+    # SDE scalars
+    ts = torch.linspace(0.0, 1.0, 9)
+    ts_in = torch.linspace(0.01, 0.99, 9)
+    vp = r_sdes.VP(0.1, 10.0, 1.3, terminal_t=1.0)
+    a, b = ts_in[:-1], ts_in[1:]
+    out.update(sc_ts=ts_in, vp_alpha=vp.alpha_(ts_in), vp_s=vp.s(ts_in), vp_sigma_sq=vp.sigma_sq(ts_in),
+               vp_diff=vp.diff_coeff_t(ts_in), vp_drift=vp.drift_coeff_t(ts_in), vp_omega=vp.omega(a, b),
+               vp_lambda=vp.lambda_(a, b), vp_omega_ddpm=vp.omega_ddpm(a, b), vp_int_drift=vp.int_drift_coeff_t(a, b),
+               vp_log_snr=vp.log_snr(ts_in))
+    meta["vp"] = dict(beta_min=0.1, beta_max=10.0, sigma=1.3, T=1.0)
+    pbm = r_sdes.PinnedBM(diff_coeff=math.sqrt(0.2), terminal_t=5.0)
+    tp = torch.linspace(0.05, 4.9, 9)
+    ap, bp = tp[:-1], tp[1:]
+    out.update(pbm_ts=tp, pbm_s=pbm.s(tp), pbm_sigma_sq=pbm.sigma_sq(tp), pbm_omega=pbm.omega(ap, bp),
+               pbm_omega_ddpm=pbm.omega_ddpm(ap, bp), pbm_drift=pbm.drift_coeff_t(tp), pbm_log_snr=pbm.log_snr(tp))
+    xx = torch.randn(4, 6)
+    sc = torch.randn(4, 6)
+    z = torch.randn(4, 6)
+    out.update(step_x=xx, step_sc=sc, step_z=z,
+               vp_ei=vp.ei_integration_step(xx, a[3], b[3], sc, z=z)[0],
+               vp_ddpm=vp.ddpm_integration_step(xx, a[3], b[3], sc, z=z)[0],
+               pbm_ei=pbm.ei_integration_step(xx, ap[3], bp[3], sc, z=z)[0],
+               pbm_ddpm=pbm.ddpm_integration_step(xx, ap[3], bp[3], sc, z=z)[0])
+    # time grids (utils/common.py:30-82)
+    out.update(ts_uniform=r_get_timesteps(0.0, 1.0, steps=10), ts_cosine=r_get_timesteps(0.0, 6.4, dt=0.05, rescale_t="cosine"),
+               ts_quad=r_get_timesteps(0.0, torch.tensor(2.0), steps=10, rescale_t="quad"),
+               ts_snr_vp=r_get_timesteps(1e-4, 1.0 - 1e-4, steps=12, sde=r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)),
+               ts_snr_pbm=r_get_timesteps(1e-4, 5.0 - 1e-4, steps=12, sde=pbm))
+    # net forward (models/mlp.py:135-143, :85-96)
+    net = liven(fourier_mlp(12))
+    tt = torch.tensor(0.37)
+    with torch.no_grad():
+        out.update(net_t=tt, net_x=x, net_out=net(tt, x), temb_out=net.timestep_embed(tt.view(1, 1)))
+    out.update(**pack_params("net.", sd(net)))
+    sm = score_time_embed(bias=0.2)
+    with torch.no_grad():
+        out.update(sm_out=sm(tt), **pack_params("sm.", sd(sm)))
+    # marginal GMM score at a time (eq/sdes.py:329-345)
+    vp1 = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
+    mv = 0.5 * torch.ones(5, 12) * (1 + 0.3 * torch.rand(5, 12))
+    out.update(mg_vars=mv, mg_score=vp1.marginal_gmm_score(torch.tensor(0.41), x, tgt.loc, mv, torch.ones(5)),
+               mg_logp0=vp1.marginal_gmm_distr(torch.tensor(0.0), tgt.loc, mv, torch.ones(5)).log_prob(x))
+    save("unit_vectors", dict(kind="unit", **meta), out)
+
+
+def main():
+    unit_vectors()
+    # config 2 family (ManyModes d=128, RDS gmm-ref, VP, EI)
+    case_rds_gmm("rds_ei_gmm_d128_k4", d=128, K=4, B=64, N=16, seed=11)
+    case_rds_gmm("rds_ei_gmm_d128_k4_n256", d=128, K=4, B=32, N=256, seed=12)
+    case_rds_gmm("rds_ei_gmm_d128_k16", d=128, K=16, B=32, N=32, seed=13)
+    case_rds_gmm("rds_ei_gmm_d8_k4", d=8, K=4, B=96, N=100, seed=14)
+    case_rds_gmm("rds_ddpm_gmm_d16_snr", d=16, K=4, B=64, N=32, seed=15, integrator="ddpm_like", time_type="snr")
+    case_rds_gmm("rds_em_gmm_d16", d=16, K=4, B=64, N=64, seed=16, integrator="em")
+    case_rds_default("rds_em_vp_default_d16", d=16, K=4, B=64, N=64, seed=17, sde_kind="vp", integrator="em")
+    case_rds_default("rds_ei_vp_default_d16", d=16, K=4, B=64, N=32, seed=18, sde_kind="vp", integrator="ei")
+    case_rds_default("rds_ei_pbm_default_d16", d=16, K=4, B=64, N=32, seed=19, sde_kind="pbm", integrator="ei")
+    # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
+    case_pis_phi4("pis_em_phi4_d100", d=100, B=64, N=32, seed=21, dt=5.0 / 512)
+    # config 1 (TwoModes d=2, DDS)
+    case_dds("dds_two_modes_d2", d=2, B=128, seed=31)
+    # config 4 (logreg d=61, CMCD), at the real step size 1/256
+    case_cmcd_logreg("cmcd_logreg_d61", B=64, N=16, seed=41, dt=1.0 / 256)
+    # DIS variants
+    case_dis("dis_ei_d8", d=8, K=4, B=64, N=32, seed=51, kind="ei")
+    case_dis("dis_orig_lerp_d8", d=8, K=4, B=64, N=64, seed=52, kind="orig")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+"""Rebuild the golden cases of tests/golden/*.npz on top of the CPU oracle.
+
+Shared by the oracle-vs-golden tests (CPU) and the HIP-vs-oracle/golden tests (GPU).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import sde_oracle as orc
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SIM_CASES = [
+    "rds_ei_gmm_d128_k4", "rds_ei_gmm_d128_k4_n256", "rds_ei_gmm_d128_k16", "rds_ei_gmm_d8_k4",
+    "rds_ddpm_gmm_d16_snr", "rds_em_gmm_d16", "rds_em_vp_default_d16", "rds_ei_vp_default_d16",
+    "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "cmcd_logreg_d61", "dis_ei_d8",
+    "dis_orig_lerp_d8",
+]
+
+
+class Case:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.meta = json.loads(bytes(z["meta"]).decode())
+        self.a = {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+
+    def params(self, prefix):
+        return {k[len(prefix):]: v for k, v in self.a.items() if k.startswith(prefix)}
+
+    def __getitem__(self, k):
+        return self.a[k]
+
+
+def load(name) -> Case:
+    return Case(name)
+
+
+def make_sde(m):
+    if m.get("sde", "vp") == "pbm":
+        return orc.PinnedBM(m["diff_coeff"], m["T"])
+    return orc.VP(m["beta_min"], m["beta_max"], m["sigma"], m["T"])
+
+
+def run_oracle(c: Case, noise=None, B=None):
+    """Run the oracle's restatement of case ``c`` -> (x_N, rnd).  ``noise`` defaults to the
+    counter-based replay the fixture was generated with."""
+    m = c.meta
+    x0 = c["x0"] if B is None else c["x0"][:B]
+    ts = c["ts"]
+    noise = noise or orc.PhiloxNoise(m["seed"])
+    kind = m["kind"]
+    if kind == "rds_gmm":
+        sde = make_sde(m)
+        tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+        ctrl = orc.Ctrl(c.params("ctrl."), "clipped", clip_model=m["clip_model"])
+        means, var, w = c["ref_means"], c["ref_vars"], c["ref_w"]
+
+        def ref_score(t, x):
+            loc, v = sde.marginal_diag(t, means, var)
+            return orc.mog_score(x, w, loc, v)
+
+        loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+        refd = orc.GMMDiag(loc0, torch.sqrt(v0), w)
+        if m["integrator"] == "em":
+            out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score, noise)
+        else:
+            out = orc.simulate_ei_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score, noise,
+                                      ddpm=(m["integrator"] == "ddpm_like"))
+    elif kind == "rds_default":
+        sde = make_sde(m)
+        tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+        ctrl = orc.Ctrl(c.params("ctrl."), "clipped", clip_model=m["clip_model"])
+        xi, vi = c["ref_x_init"], c["ref_var_init"]
+
+        def ref_score(t, x):
+            loc, v = sde.marginal_diag(t, xi, vi)
+            return orc.gauss_score(x, loc, v)
+
+        loc0, v0 = sde.marginal_diag(torch.tensor(0.0), xi, vi)
+        refd = orc.GaussDiag(loc0, v0.sqrt())
+        if m["integrator"] == "em":
+            out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score, noise)
+        else:
+            out = orc.simulate_ei_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score, noise,
+                                      ddpm=(m["integrator"] == "ddpm_like"))
+    elif kind == "pis_phi4":
+        sde = orc.ScaledBM(m["diff_coeff"], m["T"])
+        tgt = orc.PhiFour(m["a"], m["b"], m["d"], m["beta"])
+        ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score,
+                        clip_score=m["clip_score"], scale_score=m["scale_score"])
+        refd = orc.GaussDiag(c["ref_loc"], c["ref_scale"])
+        out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, None, noise)
+    elif kind == "dds":
+        tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+        prior = orc.IsoGauss(m["d"], 0.0, m["sigma"])
+        ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score,
+                        clip_score=m["clip_score"], scale_score=m["scale_score"])
+        out = orc.simulate_dds(ts, x0, ctrl, m["alpha"], m["sigma"], tgt.logp, prior.logp, noise)
+    elif kind == "cmcd_logreg":
+        tgt = orc.LogReg(c["X"], c["y"], m["weight_scale"], m["intercept_mean"], m["intercept_scale"])
+        prior = orc.GaussFull(c["prior_loc"], c["prior_cov"])
+        ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score,
+                        clip_score=m["clip_score"], scale_score=m["scale_score"])
+        out = orc.simulate_cmcd(ts, x0, ctrl, tgt.score, prior.score, m["diff_coeff"], m["T"], m["clip_langevin"],
+                                tgt.logp, prior.logp, noise)
+    elif kind in ("dis_ei", "dis_orig"):
+        sde = make_sde(m)
+        tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+        prior = orc.IsoGauss(m["d"], 0.0, 1.0)
+        if kind == "dis_ei":
+            ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score,
+                            clip_score=m["clip_score"], scale_score=m["scale_score"])
+            out = orc.simulate_dis_ei(ts, x0, ctrl, sde, tgt.logp, prior.logp, noise)
+        else:
+            ctrl = orc.Ctrl(c.params("ctrl."), "lerp", clip_model=m["clip_model"], target_score=tgt.score,
+                            clip_score=m["clip_score"], scale_score=m["scale_score"], sde=sde, prior_score=prior.score)
+            out = orc.simulate_time_reversal(ts, x0, ctrl, sde, tgt.logp, prior.logp, noise)
+    else:
+        raise KeyError(kind)
+    return out[0], out[1]
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a-b| / max(1, |b|) elementwise-scaled: relative for large values, absolute near zero."""
+    a, b = a.double(), b.double()
+    return float(((a - b).abs() / b.abs().clamp(min=1.0)).max())

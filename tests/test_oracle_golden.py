@@ -1,0 +1,138 @@
+"""Pin the CPU oracle (oracle/sde_oracle.py) against fixtures produced by the real reference
+(tests/golden/gen_golden.py).  CPU only."""
+import math
+
+import pytest
+import torch
+
+from oracle import sde_oracle as orc
+from tests import golden_cases as gc
+
+# The oracle repeats the reference's torch ops in the reference's order, so agreement is at
+# fp32 round-off; 2e-6 leaves room for accumulated last-ulp differences over <= 256 steps.
+TOL_SIM = 2e-6
+
+
+@pytest.mark.parametrize("name", gc.SIM_CASES)
+def test_simulate_matches_reference(name):
+    c = gc.load(name)
+    x, rnd = gc.run_oracle(c)
+    tol = 2e-5 if name in ("cmcd_logreg_d61",) else TOL_SIM  # hand-coded logreg gradient vs autograd
+    assert gc.rel_err(x, c["out_x"]) < tol
+    assert gc.rel_err(x, c["xs_last2"][-1]) < tol
+    assert gc.rel_err(rnd, c["rnd"]) < tol
+    res = orc.compute_results(rnd)
+    assert abs(res["log_norm_const_is"] - c.meta["log_norm_const_is"]) < 1e-4 * max(1.0, abs(c.meta["log_norm_const_is"]))
+    assert abs(res["elbo"] - c.meta["elbo"]) < 1e-4 * max(1.0, abs(c.meta["elbo"]))
+    assert gc.rel_err(res["weights"], c["out_weights"]) < 1e-4
+
+
+def test_unit_vectors():
+    c = gc.load("unit_vectors")
+    x = c["gmm_x"]
+    g = orc.GMMDiag(c["gmm_loc"], c["gmm_scale"], c["gmm_w"])
+    assert gc.rel_err(g.score(x), c["gmm_score"]) < 1e-6
+    assert gc.rel_err(g.logp(x), c["gmm_logp"]) < 1e-6
+    m = c.meta["phi"]
+    phi = orc.PhiFour(m["a"], m["b"], m["dim"], m["beta"])
+    assert gc.rel_err(phi.score(c["phi_x"]), c["phi_score"]) < 1e-6
+    assert gc.rel_err(phi.logp(c["phi_x"]), c["phi_logp"]) < 1e-6
+    rg = orc.Rings()
+    assert gc.rel_err(rg.score(c["rings_x"]), c["rings_score"]) < 1e-5
+    assert gc.rel_err(rg.logp(c["rings_x"]), c["rings_logp"]) < 1e-5
+    m = c.meta["iso"]
+    iso = orc.IsoGauss(m["dim"], m["loc"], m["scale"])
+    assert gc.rel_err(iso.logp(x), c["iso_logp"]) < 1e-6
+    assert gc.rel_err(iso.score(x), c["iso_score"]) < 1e-6
+    gd = orc.GaussDiag(c["gd_loc"], c["gd_scale"])
+    assert gc.rel_err(gd.logp(x), c["gd_logp"]) < 1e-6
+    assert gc.rel_err(gd.score(x), c["gd_score"]) < 1e-6
+    gf = orc.GaussFull(c["gf_loc"], c["gf_cov"])
+    assert gc.rel_err(gf.logp(x), c["gf_logp"]) < 1e-5
+    assert gc.rel_err(gf.score(x), c["gf_score"]) < 1e-5
+
+
+def test_sde_scalars():
+    c = gc.load("unit_vectors")
+    m = c.meta["vp"]
+    vp = orc.VP(m["beta_min"], m["beta_max"], m["sigma"], m["T"])
+    t = c["sc_ts"]
+    a, b = t[:-1], t[1:]
+    for got, key in [(vp.alpha(t), "vp_alpha"), (vp.s(t), "vp_s"), (vp.sigma_sq(t), "vp_sigma_sq"),
+                     (vp.diff_coeff(t), "vp_diff"), (vp.drift_coeff(t), "vp_drift"), (vp.omega(a, b), "vp_omega"),
+                     (vp.lam(a, b), "vp_lambda"), (vp.omega_ddpm(a, b), "vp_omega_ddpm"),
+                     (vp.int_drift_coeff(a, b), "vp_int_drift"), (vp.log_snr(t), "vp_log_snr")]:
+        assert torch.equal(got, c[key]), key
+    pbm = orc.PinnedBM(math.sqrt(0.2), 5.0)
+    tp = c["pbm_ts"]
+    ap, bp = tp[:-1], tp[1:]
+    for got, key in [(pbm.s(tp), "pbm_s"), (pbm.sigma_sq(tp), "pbm_sigma_sq"), (pbm.omega(ap, bp), "pbm_omega"),
+                     (pbm.omega_ddpm(ap, bp), "pbm_omega_ddpm"), (pbm.drift_coeff(tp), "pbm_drift"),
+                     (pbm.log_snr(tp), "pbm_log_snr")]:
+        assert torch.equal(got, c[key]), key
+    x, sc, z = c["step_x"], c["step_sc"], c["step_z"]
+    assert torch.equal(vp.ei_step(x, a[3], b[3], sc, z), c["vp_ei"])
+    assert torch.equal(vp.ddpm_step(x, a[3], b[3], sc, z), c["vp_ddpm"])
+    assert torch.equal(pbm.ei_step(x, ap[3], bp[3], sc, z), c["pbm_ei"])
+    assert torch.equal(pbm.ddpm_step(x, ap[3], bp[3], sc, z), c["pbm_ddpm"])
+
+
+def test_time_grids():
+    c = gc.load("unit_vectors")
+    assert torch.equal(orc.get_timesteps(0.0, 1.0, steps=10), c["ts_uniform"])
+    cos = orc.get_timesteps(0.0, 6.4, dt=0.05, rescale_t="cosine")
+    assert cos.numel() == 130  # steps+2 points: the reference's off-by-one (SURVEY a-9)
+    assert torch.equal(cos, c["ts_cosine"])
+    assert torch.equal(orc.get_timesteps(0.0, torch.tensor(2.0), steps=10, rescale_t="quad"), c["ts_quad"])
+    assert torch.equal(orc.get_timesteps(1e-4, 1.0 - 1e-4, steps=12, sde=orc.VP(0.1, 10.0, 1.0, 1.0)), c["ts_snr_vp"])
+    assert torch.equal(orc.get_timesteps(1e-4, 5.0 - 1e-4, steps=12, sde=orc.PinnedBM(math.sqrt(0.2), 5.0)), c["ts_snr_pbm"])
+
+
+def test_net_forward():
+    c = gc.load("unit_vectors")
+    p = c.params("net.")
+    out = orc.fourier_mlp(p, "", c["net_t"], c["gmm_x"])
+    assert gc.rel_err(out, c["net_out"]) < 1e-6
+    te = orc.time_embed(p, "timestep_embed.", c["net_t"].view(1, 1))
+    assert gc.rel_err(te, c["temb_out"]) < 1e-6
+    sm = orc.time_embed(c.params("sm."), "", c["net_t"])
+    assert gc.rel_err(sm, c["sm_out"]) < 1e-6
+
+
+def test_marginal_gmm():
+    c = gc.load("unit_vectors")
+    vp = orc.VP(0.1, 10.0, 1.0, 1.0)
+    loc, var = vp.marginal_diag(torch.tensor(0.41), c["gmm_loc"], c["mg_vars"])
+    assert gc.rel_err(orc.mog_score(c["gmm_x"], torch.ones(5), loc, var), c["mg_score"]) < 1e-6
+    loc0, var0 = vp.marginal_diag(torch.tensor(0.0), c["gmm_loc"], c["mg_vars"])
+    assert gc.rel_err(orc.GMMDiag(loc0, var0.sqrt(), torch.ones(5)).logp(c["gmm_x"]), c["mg_logp0"]) < 1e-6
+
+
+def test_logreg_closed_form_score_matches_autograd_fixture():
+    """The reference's logreg score is autograd through clip/clamp (distr/base.py:146-154); the oracle's
+    closed form must reproduce it, including rows with saturated probabilities (inputs scaled 5x, 30x)."""
+    c = gc.load("cmcd_logreg_d61")
+    m = c.meta
+    lr = orc.LogReg(c["X"], c["y"], m["weight_scale"], m["intercept_mean"], m["intercept_scale"])
+    assert gc.rel_err(lr.score(c["score_x"]), c["score_out"]) < 5e-6
+    assert gc.rel_err(lr.logp(c["score_x"]), c["logp_out"]) < 1e-6
+    pr = orc.GaussFull(c["prior_loc"], c["prior_cov"])
+    assert gc.rel_err(pr.logp(c["x0"]), c["prior_logp_x0"]) < 1e-5
+    assert gc.rel_err(pr.score(c["x0"]), c["prior_score_x0"]) < 1e-5
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors)."""
+    import numpy as np
+    r = orc.philox4x32_10(np.uint32(0), np.uint32(0), np.uint32(0), np.uint32(0), 0, 0)
+    assert [int(v) for v in r] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    f = np.uint32(0xFFFFFFFF)
+    r = orc.philox4x32_10(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF)
+    assert [int(v) for v in r] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    r = orc.philox4x32_10(np.uint32(0x243F6A88), np.uint32(0x85A308D3), np.uint32(0x13198A2E), np.uint32(0x03707344),
+                          0xA4093822, 0x299F31D0)
+    assert [int(v) for v in r] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    z = orc.philox_normal(5, 3, 0, 4096, 16)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    # sharding independence: particles [100, 164) drawn alone equal the slice of the full batch
+    assert torch.equal(orc.philox_normal(5, 3, 100, 64, 16), z[100:164])
