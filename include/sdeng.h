@@ -1,0 +1,214 @@
+/*
+ * sdeng.h -- C ABI of the MI355X-native SDE sampling engine (libsdeng.so).
+ *
+ * The reference (vanilladucky/sde_sampler_lrds) has no FFI: its seam for this path is the
+ * Python callable protocol of sde_sampler/losses/oc.py (`loss.simulate(ts, x, ...)`,
+ * SURVEY.md section 8b).  This header is the binding a maintainer would add below that seam:
+ * one call per `simulate()` loop, plain pointers and sizes, no torch types.  Every entry point
+ * names the reference code it replaces (paths relative to /root/reference/sde_sampler).
+ *
+ * Conventions
+ *   - all arrays are fp32, row-major, contiguous, in DEVICE memory unless noted;
+ *   - the callee borrows every pointer for the duration of the stream-ordered work and never
+ *     frees or allocates: outputs and the workspace are caller-allocated;
+ *   - every function enqueues on `stream` (a hipStream_t) and returns without synchronising;
+ *   - return value 0 = ok, negative = error (see SDENG_E_*); the message for the calling
+ *     thread's last error is available from sdeng_last_error(); nothing ever throws;
+ *   - re-entrant per stream; the only global state is the thread-local error string.
+ */
+#ifndef SDENG_H
+#define SDENG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDENG_ABI_VERSION 1
+
+/* error codes */
+#define SDENG_OK 0
+#define SDENG_E_INVALID (-1)     /* malformed descriptor (null pointer, bad size)          */
+#define SDENG_E_UNSUPPORTED (-2) /* valid, but no kernel is built for this combination      */
+#define SDENG_E_WORKSPACE (-3)   /* workspace too small (see sdeng_workspace_bytes)          */
+#define SDENG_E_HIP (-4)         /* a HIP runtime call failed                                */
+
+/* ---- which simulate() loop -------------------------------------------------------------
+ * SDENG_FORM_LIN   x' = (c1*x + c2*(u [+ ref])) + c3*z ;  rnd += c4*<u,u> + c5*<u,z> + c6
+ *                  EIReferenceSDELoss.simulate        losses/oc.py:444-510  (+ eq/sdes.py:532-539, 658-666)
+ *                  DDPMLikeReferenceSDELoss.simulate  losses/oc.py:584-651  (+ eq/sdes.py:541-555, 668-678)
+ *                  DiscreteTimeReversalLossEI.simulate losses/oc.py:906-978
+ *                  ExponentialIntegratorSDELoss.simulate losses/oc.py:1319-1397 (DDS)
+ * SDENG_FORM_EM    x' = x + ((c1*x [+ c3*ref]) + c2*u)*c4 + c2*(c5*z) ; rnd += 0.5*<u,u>*c4 + <u,c5*z> + c6
+ *                  EMReferenceSDELoss.simulate        losses/oc.py:218-296  (PIS: no reference)
+ *                  TimeReversalLoss.simulate          losses/oc.py:1133-1238 (no inference control)
+ * SDENG_FORM_CMCD  ControlledLangevinSDELoss.simulate losses/oc.py:666-755 (+ eq/sdes.py:101-110)
+ */
+#define SDENG_FORM_LIN 0
+#define SDENG_FORM_EM 1
+#define SDENG_FORM_CMCD 2
+
+/* Per-step coefficient table: coef[N][SDENG_NCOEF], filled by the host with the reference's own
+ * fp32 scalar formulas (eq/sdes.py:456-555, 609-678; losses/oc.py:1369-1371).  Column meaning:
+ *            LIN              EM                 CMCD
+ *   [0]  t_net            t_net              s            time fed to the drift net
+ *   [1]  c1 (x gain)      c1 (+-drift coef)  t            (CMCD: time of the second evaluation)
+ *   [2]  c2 (ctrl gain)   c2 = g             dt
+ *   [3]  c3 (noise gain)  c3 = g^2           sqrt(dt)
+ *   [4]  c4 (0.5*omega)   c4 = dt            s/T
+ *   [5]  c5 (sqrt omega)  c5 = sqrt(dt)      1 - s/T
+ *   [6]  c6 (rnd const)   c6 (rnd const)     t/T
+ *   [7]  score gain       score gain         1 - t/T      LerpCtrl: g(t); ScoreCtrl: 1
+ *   [8]  lerp weight t/T  lerp weight        (unused)     LerpCtrl only
+ *   [9]  s(tau)   [10] s(tau)^2*sigma_sq(tau)   [11] s(tau)^2   reference marginal (eq/sdes.py:228-229,247)
+ *   [12..15] reserved
+ */
+#define SDENG_NCOEF 16
+
+/* flags */
+#define SDENG_FLAG_ITO 1u          /* accumulate the stochastic integral <u,z> (compute_ito_int)     */
+#define SDENG_FLAG_INIT_LOGP 2u    /* rnd0 = log p_prior(x0)  (losses/oc.py:695-699, 935-939, 1164-1168) */
+#define SDENG_FLAG_TERM_REF 4u     /* terminal: rnd += log p_ref(x_N)  (losses/oc.py:290, 505, 645, 1390) */
+#define SDENG_FLAG_TERM_TARGET 8u  /* terminal: rnd -= log pi~(x_N)                                 */
+
+/* ---- distributions (the distr package): log-density and score by hand-coded formulas ------------ */
+#define SDENG_DIST_NONE 0
+#define SDENG_DIST_GMM_DIAG 1   /* distr/gauss.py:138-244  GMM / TwoModes / ManyModes (MixtureSameFamily)   */
+#define SDENG_DIST_GAUSS_DIAG 2 /* distr/gauss.py:597-629  Gauss, Delta (one component, no mixture weights) */
+#define SDENG_DIST_ISO_GAUSS 3  /* distr/gauss.py:720-787  IsotropicGauss                                   */
+#define SDENG_DIST_PHI4 4       /* distr/phi_four.py:8-96  1-D lattice, Dirichlet-0 boundary                */
+#define SDENG_DIST_LOGREG 5     /* distr/logistic_regression.py:11-92 + autograd score distr/base.py:146-154 */
+#define SDENG_DIST_GAUSS_FULL 6 /* distr/gauss.py:632-717  GaussFull (MultivariateNormal)                   */
+
+typedef struct sdeng_dist {
+  int32_t kind;      /* SDENG_DIST_*                                                              */
+  int32_t k;         /* GMM: number of components; LOGREG: number of data rows                    */
+  const float* loc;  /* GMM [k,d]; GAUSS_DIAG/GAUSS_FULL [d]; LOGREG: X [k,d-1]                   */
+  const float* scale;/* GMM [k,d]; GAUSS_DIAG [d] (std-dev); GAUSS_FULL: precision [d,d]; LOGREG: y [k] */
+  const float* w;    /* GMM: unnormalised mixture weights [k]; GAUSS_FULL: inverse Cholesky factor L^-1 [d,d] */
+  float p0, p1, p2, p3; /* ISO_GAUSS: loc, scale, norm_const = -0.5*d*log(2*pi*scale^2), scale^2 (both as the
+                           reference computes them in fp32, distr/gauss.py:759-760); PHI4: a, b, beta;
+                           LOGREG: weight_scale, intercept_mean, intercept_scale, threshold;
+                           GAUSS_FULL: p0 = sum(log diag L) */
+  float clip;        /* clip applied to the log-density (solver/oc.py:80-87 clip_target); <=0: none */
+} sdeng_dist;
+
+/* ---- drift net: models/mlp.py:99-143 FourierMLP(num_layers=4, channels=64, GELU) wrapped by
+ *      models/reparam.py:18-43 ClippedCtrl / :63-117 ScoreCtrl / :148-199 LerpCtrl ------------ */
+#define SDENG_CTRL_CLIPPED 0
+#define SDENG_CTRL_SCORE 1
+#define SDENG_CTRL_LERP 2
+#define SDENG_HIDDEN 64
+
+typedef struct sdeng_time_embed { /* models/mlp.py:57-96 TimeEmbed */
+  const float* coeff;             /* timestep_coeff [64] (linspace(0.1,100,64))          */
+  const float* phase;             /* timestep_phase [64]                                  */
+  const float* w[4];              /* hidden_layer[i].weight: [64,128] for i=0, [64,64] after */
+  const float* b[4];              /* hidden_layer[i].bias [64]                            */
+  int32_t n_hidden;               /* num_layers - 1 (1 for the MLP's embed, 3 for score_model) */
+  int32_t dim_out;                /* 64 (MLP embed) or 1 (score_model)                    */
+  const float* w_out;             /* out_layer.weight [dim_out,64]                        */
+  const float* b_out;             /* out_layer.bias [dim_out]                             */
+} sdeng_time_embed;
+
+typedef struct sdeng_net {
+  int32_t ctrl_kind;              /* SDENG_CTRL_*                                         */
+  int32_t reserved;
+  const float *w_in, *b_in;       /* input_embed  [64,d], [64]                            */
+  const float *w_h1, *b_h1;       /* hidden_layer.0 [64,64], [64]                         */
+  const float *w_h2, *b_h2;       /* hidden_layer.1 [64,64], [64]                         */
+  const float *w_out, *b_out;     /* out_layer [d,64], [d]                                */
+  sdeng_time_embed t_embed;       /* base_model.timestep_embed (dim_out 64)               */
+  sdeng_time_embed score_model;   /* ScoreCtrl/LerpCtrl score_model (dim_out 1); n_hidden=0: absent */
+  float clip_model;               /* reparam.py:33-40; <=0: no clipping                   */
+  float clip_score;               /* reparam.py:91-100; <=0: none                         */
+  float scale_score;              /* reparam.py:114                                       */
+  float reserved_f;
+} sdeng_net;
+
+/* ---- reference drift (solver/oc.py:535-576 change_reference_type -> eq/sdes.py:265-345) ---- */
+#define SDENG_REF_NONE 0
+#define SDENG_REF_GAUSS_DIAG 1 /* marginal_score, diagonal var_init            eq/sdes.py:265-279 */
+#define SDENG_REF_GMM_DIAG 2   /* marginal_gmm_score, diagonal variances_init  eq/sdes.py:329-345 */
+
+typedef struct sdeng_ref {
+  int32_t kind;
+  int32_t k;               /* GMM components (1 for GAUSS_DIAG)                      */
+  const float* means_init; /* [k,d]                                                   */
+  const float* vars_init;  /* [k,d]                                                   */
+  const float* weights;    /* [k] unnormalised (normalised like distr/gauss.py:100)   */
+} sdeng_ref;
+
+/* ---- noise ---------------------------------------------------------------------------------
+ * noise_in != NULL : injected, z[k] = noise_in[k*B*d ...] -- replays the reference's one
+ *                    randn_like(x) per step (losses/oc.py:277, eq/sdes.py:537, losses/oc.py:722, 1372, 1222);
+ * noise_in == NULL : counter-based Philox4x32-10, counter (step, feature/4, particle0+p, stream), key = seed,
+ *                    two Box-Muller pairs on u = ((bits>>9)+0.5)*2^-23; independent of sharding.
+ */
+typedef struct sdeng_desc {
+  int32_t abi_version;   /* SDENG_ABI_VERSION                                              */
+  int32_t form;          /* SDENG_FORM_*                                                   */
+  uint32_t flags;        /* SDENG_FLAG_*                                                   */
+  int32_t B, d, N;       /* particles (this shard), dimension (<=128), steps               */
+  int64_t particle0;     /* global index of this shard's first particle (Philox counter)   */
+  uint64_t seed;         /* Philox key                                                     */
+  const float* coef;     /* [N][SDENG_NCOEF], device                                        */
+  const float* x_in;     /* [B,d]                                                           */
+  float* x_out;          /* [B,d]                                                           */
+  float* rnd_out;        /* [B]  (the reference's rnd[B,1])                                 */
+  float* xs_out;         /* optional trajectory [N+1,B,d] (return_traj=True), or NULL       */
+  const float* noise_in; /* optional [N,B,d], or NULL                                       */
+  sdeng_net net;
+  sdeng_ref ref;
+  sdeng_dist target;     /* terminal cost + (ScoreCtrl/LerpCtrl/CMCD) target score          */
+  sdeng_dist ref_dist;   /* terminal reference log-density (FLAG_TERM_REF)                  */
+  sdeng_dist prior;      /* initial log-density (FLAG_INIT_LOGP); LerpCtrl/CMCD prior score  */
+  float cmcd_g;          /* ControlledLangevinSDE.diff_coeff          eq/sdes.py:93-95     */
+  float cmcd_clip;       /* ControlledLangevinSDE.clip_score (<=0: none) eq/sdes.py:105-110 */
+  void* workspace;       /* device scratch, >= sdeng_workspace_bytes(desc)                  */
+  size_t workspace_bytes;
+} sdeng_desc;
+
+/* Version of this ABI compiled into the library. */
+int sdeng_abi_version(void);
+
+/* Message of the calling thread's most recent error ("" if none). */
+const char* sdeng_last_error(void);
+
+/* Device scratch needed by sdeng_simulate for this descriptor (packed MFMA weight image,
+ * per-step embedding and reference tables).  Pure host arithmetic; 0 on a malformed descriptor. */
+size_t sdeng_workspace_bytes(const sdeng_desc* desc);
+
+/* Run one whole simulate() loop (all N steps, initial and terminal cost) on `stream`.
+ * Replaces the Python step loops listed under SDENG_FORM_*. */
+int sdeng_simulate(const sdeng_desc* desc, void* stream);
+
+/* Estimators of BaseOCLoss.compute_results (losses/oc.py:150-161) and the normalised ESS of
+ * eval/metrics.py:135-140 from rnd[B]:
+ *   stats[0] = mean(-rnd) (elbo)      stats[1] = logsumexp(-rnd) - log(B) (log_norm_const_is)
+ *   stats[2] = var(rnd) (unbiased)    stats[3] = (sum w)^2 / sum w^2 / B  with w = softmax(-rnd)
+ *   stats[4] = max(-rnd)              stats[5] = sum exp(-rnd - max)      stats[6] = sum exp(2(-rnd - max))
+ *   stats[7] = sum(-rnd)              (4..7: partials for the multi-GPU combine)
+ * weights_out (optional, [B]) receives softmax(-rnd, 0).  stats is device memory, 8 floats. */
+int sdeng_logz(const float* rnd, int64_t B, float* stats, float* weights_out, void* workspace, size_t workspace_bytes,
+               void* stream);
+size_t sdeng_logz_workspace_bytes(void);
+
+/* Standalone pieces, exported for unit parity tests against the oracle:
+ * FourierMLP (+ctrl wrapper) forward at one time, u[B,d] (models/mlp.py:135-143, reparam.py:42,112-117,186-199) */
+int sdeng_ctrl_forward(const sdeng_desc* desc, float t_net, float score_gain, float lerp_w, const float* x, float* u_out,
+                       void* stream);
+/* distribution log-density [B] and score [B,d] (either output may be NULL) */
+int sdeng_dist_eval(const sdeng_dist* dist, int32_t B, int32_t d, const float* x, float* logp_out, float* score_out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t sdeng_dist_workspace_bytes(const sdeng_dist* dist, int32_t d);
+/* Counter-based normals exactly as the step loop draws them: out[B,d] for one step. */
+int sdeng_philox_normal(uint64_t seed, int32_t step, int64_t particle0, int32_t B, int32_t d, uint32_t stream_id,
+                        float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDENG_H */

@@ -1,0 +1,528 @@
+// Small per-call kernels around the persistent simulate kernel (gfx950):
+//   k_pack_mlp      nn.Linear weights -> LDS image of MFMA A operands          (models/mlp.py:99-143 parameters)
+//   k_time_embed    TimeEmbed.forward for all N step times at once              (models/mlp.py:85-96)
+//   k_ref_tables    noised reference marginals per step                          (eq/sdes.py:208-248, 281-307)
+//   k_dist_tables   static tables of a diagonal Gaussian / mixture               (distr/gauss.py:67-73, 217-221)
+//   k_dist_eval     log-density / score of any supported distribution            (distr/*.py)
+//   k_terminal      rnd += log p_ref(x_N) - log pi~(x_N)                         (losses/oc.py:290, 505, 973)
+//   k_logz_*        elbo / logsumexp / variance / ESS / softmax weights          (losses/oc.py:150-161)
+//   k_philox        the step loop's counter-based normals, standalone            (tests)
+#include "sim_device.hpp"
+#include "prep_kernels.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// weights -> packed LDS image.  One thread per packed float.
+// ------------------------------------------------------------------------------------------------
+__device__ inline float pack_fetch(const float* W, int n_out, int n_in, int to, int ti, int r, int lane) {
+  const int o = 32 * to + (lane & 31);
+  const int i = feat(ti, r, lane >> 5);
+  return (o < n_out && i < n_in) ? W[static_cast<size_t>(o) * n_in + i] : 0.0f;
+}
+
+__global__ void k_pack_mlp(PackArgs a) {
+  const int DT = a.DT;
+  const int total = sd_lds_floats(DT);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    float v;
+    if (idx < sd_off_bias(DT)) {
+      // which layer
+      const float* W;
+      int n_out, n_in, TI, local;
+      if (idx < sd_off_wh1(DT)) {
+        W = a.w_in; n_out = SD_H; n_in = a.d; TI = DT; local = idx - sd_off_win(DT);
+      } else if (idx < sd_off_wh2(DT)) {
+        W = a.w_h1; n_out = SD_H; n_in = SD_H; TI = 2; local = idx - sd_off_wh1(DT);
+      } else if (idx < sd_off_wout(DT)) {
+        W = a.w_h2; n_out = SD_H; n_in = SD_H; TI = 2; local = idx - sd_off_wh2(DT);
+      } else {
+        W = a.w_out; n_out = a.d; n_in = SD_H; TI = 2; local = idx - sd_off_wout(DT);
+      }
+      // local = (((to*TI + ti)*4 + r4)*64 + lane)*4 + e
+      const int e = local & 3;
+      const int lane = (local >> 2) & 63;
+      const int r4 = (local >> 8) & 3;
+      const int pair = local >> 10;
+      const int ti = pair % TI, to = pair / TI;
+      v = pack_fetch(W, n_out, n_in, to, ti, 4 * r4 + e, lane);
+    } else {
+      const int b = idx - sd_off_bias(DT);
+      if (b < 64) v = a.b_in[b];
+      else if (b < 128) v = a.b_h1[b - 64];
+      else if (b < 192) v = a.b_h2[b - 128];
+      else v = (b - 192 < a.d) ? a.b_out[b - 192] : 0.0f;
+    }
+    a.out[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TimeEmbed.forward (models/mlp.py:85-96) for every step time: grid = N blocks of 64 threads.
+// t comes from coef[k][col]; out[k][dim_out]; optional clip (score_model: reparam.py:102-110).
+// ------------------------------------------------------------------------------------------------
+__device__ inline float gelu_exact(float v) { return (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__global__ void __launch_bounds__(64) k_time_embed(TimeEmbedArgs a) {
+  __shared__ float e[128];
+  __shared__ float hbuf[2][64];
+  const int k = blockIdx.x, j = threadIdx.x;
+  const float t = a.t_direct ? a.t_value : a.coef[static_cast<size_t>(k) * SDENG_NCOEF + a.col];
+  const float arg = (a.te.coeff[j] * t) + a.te.phase[j];
+  e[j] = sinf(arg);
+  e[64 + j] = cosf(arg);
+  __syncthreads();
+  const float* in = e;
+  int n_in = 128, cur = 0;
+  for (int l = 0; l < a.te.n_hidden; ++l) {
+    const float* W = a.te.w[l] + static_cast<size_t>(j) * n_in;
+    float acc = 0.0f;
+    for (int i = 0; i < n_in; ++i) acc = __builtin_fmaf(W[i], in[i], acc);
+    acc += a.te.b[l][j];
+    hbuf[cur][j] = gelu_exact(acc);
+    __syncthreads();
+    in = hbuf[cur];
+    n_in = 64;
+    cur ^= 1;
+  }
+  if (j < a.te.dim_out) {
+    const float* W = a.te.w_out + static_cast<size_t>(j) * 64;
+    float acc = 0.0f;
+    for (int i = 0; i < 64; ++i) acc = __builtin_fmaf(W[i], in[i], acc);
+    acc += a.te.b_out[j];
+    if (a.clip > 0.0f) acc = clampf(acc, a.clip);
+    a.out[static_cast<size_t>(k) * a.te.dim_out + j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference marginals per step (eq/sdes.py:228-229, 247): mean = s*m, var = s^2 sigma^2 + s^2 v.
+// tab[k][c][0][f] = mean, tab[k][c][1][f] = 1/var (0 on pad features); consts[k][c] = (0.5*sum log var, log w_c).
+// grid = N*K blocks of 128 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_ref_tables(RefTabArgs a) {
+  __shared__ float red[128];
+  const int k = blockIdx.x / a.K, c = blockIdx.x % a.K;
+  const float S = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 9];
+  const float VA = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 10];
+  const float S2 = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 11];
+  float* tm = a.tab + (static_cast<size_t>(k) * a.K + c) * 2 * a.dpad;
+  float* tv = tm + a.dpad;
+  float ls = 0.0f;
+  for (int f = threadIdx.x; f < a.dpad; f += 128) {
+    float mean = 0.0f, iv = 0.0f;
+    if (f < a.d) {
+      mean = S * a.means[static_cast<size_t>(c) * a.d + f];
+      const float var = VA + S2 * a.vars[static_cast<size_t>(c) * a.d + f];
+      iv = 1.0f / var;
+      ls += logf(var);
+    }
+    tm[f] = mean;
+    tv[f] = iv;
+  }
+  red[threadIdx.x] = ls;
+  __syncthreads();
+  for (int s = 64; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float wsum = 0.0f;
+    for (int i = 0; i < a.K; ++i) wsum += a.weights ? a.weights[i] : 1.0f;
+    const float w = (a.weights ? a.weights[c] : 1.0f) / wsum;  // distr/gauss.py:100 (normalised in place upstream)
+    float* cs = a.consts + (static_cast<size_t>(k) * a.K + c) * 2;
+    cs[0] = 0.5f * red[0];
+    cs[1] = logf(w);
+  }
+}
+
+// static tables of a diagonal Gaussian / mixture: tab[c][0][f] = loc, tab[c][1][f] = 1/scale^2;
+// consts[c] = (0.5*sum log var, log w_norm, sum log scale + d*log sqrt(2pi), log-mixture-prob)
+__global__ void __launch_bounds__(128) k_dist_tables(DistTabArgs a) {
+  __shared__ float red[2][128];
+  const int c = blockIdx.x;
+  float* tm = a.tab + static_cast<size_t>(c) * 2 * a.dpad;
+  float* tv = tm + a.dpad;
+  float lv = 0.0f, lsig = 0.0f;
+  for (int f = threadIdx.x; f < a.dpad; f += 128) {
+    float mean = 0.0f, iv = 0.0f;
+    if (f < a.d) {
+      mean = a.loc[static_cast<size_t>(c) * a.d + f];
+      const float sc = a.scale[static_cast<size_t>(c) * a.d + f];
+      const float var = sc * sc;
+      iv = 1.0f / var;
+      lv += logf(var);
+      lsig += logf(sc);
+    }
+    tm[f] = mean;
+    tv[f] = iv;
+  }
+  red[0][threadIdx.x] = lv;
+  red[1][threadIdx.x] = lsig;
+  __syncthreads();
+  for (int s = 64; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* cs = a.consts + static_cast<size_t>(c) * 4;
+    cs[0] = 0.5f * red[0][0];
+    cs[2] = red[1][0] + static_cast<float>(a.d) * 0.91893853320467274178f;  // log sqrt(2 pi)
+    if (a.weights) {
+      float wsum = 0.0f;
+      for (int i = 0; i < a.K; ++i) wsum += a.weights[i];
+      const float pr = a.weights[c] / wsum;
+      cs[1] = logf(pr);
+      // Categorical(probs).logits = log(clamp(probs, eps, 1-eps)); MixtureSameFamily adds log_softmax of it
+      const float eps = 1.1920928955078125e-07f;
+      float lse_m = -INFINITY, lse_s = 0.0f;
+      for (int i = 0; i < a.K; ++i) {
+        const float li = logf(fminf(fmaxf(a.weights[i] / wsum, eps), 1.0f - eps));
+        const float m = fmaxf(lse_m, li);
+        lse_s = lse_s * expf(lse_m - m) + expf(li - m);
+        lse_m = m;
+      }
+      const float lc = logf(fminf(fmaxf(pr, eps), 1.0f - eps));
+      cs[3] = lc - (lse_m + logf(lse_s));
+    } else {
+      cs[1] = 0.0f;
+      cs[3] = 0.0f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-density / score of a distribution, one thread per particle (runs once per trajectory or in
+// unit tests; the in-loop scores live in the simulate kernels).
+// ------------------------------------------------------------------------------------------------
+__device__ float dist_logp_row(const DistEvalArgs& a, const float* x) {
+  const int d = a.d;
+  const DistDev& ds = a.ds;
+  float out = 0.0f;
+  if (ds.kind == SDENG_DIST_GMM_DIAG || ds.kind == SDENG_DIST_GAUSS_DIAG) {
+    // distr/gauss.py:217-221 -> MixtureSameFamily.log_prob: Normal.log_prob summed + log mixture, logsumexp
+    float m_run = -INFINITY, l_run = 0.0f;
+    for (int c = 0; c < ds.k; ++c) {
+      const float* tm = ds.tab + static_cast<size_t>(c) * 2 * a.dpad;
+      const float* tv = tm + a.dpad;
+      float part = 0.0f;
+      for (int f = 0; f < d; ++f) {
+        const float dl = x[f] - tm[f];
+        part = __builtin_fmaf(dl * dl, tv[f], part);
+      }
+      float lp = (-0.5f * part) - ds.consts[4 * c + 2];
+      if (ds.kind == SDENG_DIST_GAUSS_DIAG) { m_run = lp; l_run = 1.0f; break; }
+      lp += ds.consts[4 * c + 3];
+      const float m_new = fmaxf(m_run, lp);
+      l_run = l_run * expf(m_run - m_new) + expf(lp - m_new);
+      m_run = m_new;
+    }
+    out = m_run + logf(l_run);
+  } else if (ds.kind == SDENG_DIST_ISO_GAUSS) {
+    // distr/gauss.py:757-762; p0 = loc, p1 = scale, p2 = -0.5*d*log(2 pi var) (host), p3 = var
+    float part = 0.0f;
+    for (int f = 0; f < d; ++f) {
+      const float dl = x[f] - ds.p0;
+      part = __builtin_fmaf(dl, dl, part);
+    }
+    out = ds.p2 - (0.5f * part) / ds.p3;
+  } else if (ds.kind == SDENG_DIST_PHI4) {
+    // distr/phi_four.py:44-79, 92-93
+    const float coef = ds.p0 * static_cast<float>(d);
+    float grad = 0.0f, V = 0.0f, prev = 0.0f;
+    for (int f = 0; f < d; ++f) {
+      const float xv = x[f];
+      const float dl = xv - prev;
+      grad += (dl * dl) * 0.5f;
+      const float om = 1.0f - xv * xv;
+      V += (om * om) * 0.25f + ds.p1 * xv;
+      prev = xv;
+    }
+    grad += (prev * prev) * 0.5f;
+    out = (-ds.p2) * (grad * coef + V / coef);
+  } else if (ds.kind == SDENG_DIST_GAUSS_FULL) {
+    // distr/gauss.py:677-699 -> MultivariateNormal.log_prob: -0.5*(d log 2pi + |L^-1 (x-mu)|^2) - sum log diag L
+    // aux0 = loc [d], aux1 = L^-1 [d,d] (lower), p0 = sum log diag L
+    float m2 = 0.0f;
+    for (int i = 0; i < d; ++i) {
+      float yi = 0.0f;
+      const float* Li = ds.aux1 + static_cast<size_t>(i) * d;
+      for (int j = 0; j <= i; ++j) yi = __builtin_fmaf(Li[j], x[j] - ds.aux0[j], yi);
+      m2 = __builtin_fmaf(yi, yi, m2);
+    }
+    out = -0.5f * (static_cast<float>(d) * 1.8378770664093453f + m2) - ds.p0;
+  } else if (ds.kind == SDENG_DIST_LOGREG) {
+    // distr/logistic_regression.py:41-61; aux0 = X [n,d-1], aux1 = y [n]; p0 = weight_scale, p1 = intercept_mean,
+    // p2 = intercept_scale, p3 = threshold
+    const int dw = d - 1;
+    const float c = x[dw];
+    float prior = 0.0f;
+    const float lws = logf(ds.p0), two_ws2 = 2.0f * (ds.p0 * ds.p0);
+    for (int f = 0; f < dw; ++f) prior += (-(x[f] * x[f]) / two_ws2 - lws) - 0.91893853320467274178f;
+    const float dc = c - ds.p1;
+    prior += (-(dc * dc) / (2.0f * (ds.p2 * ds.p2)) - logf(ds.p2)) - 0.91893853320467274178f;
+    const float eps = 1.1920928955078125e-07f;
+    float ll = 0.0f;
+    for (int n = 0; n < ds.k; ++n) {
+      const float* Xn = ds.aux0 + static_cast<size_t>(n) * dw;
+      float lg = 0.0f;
+      for (int f = 0; f < dw; ++f) lg = __builtin_fmaf(Xn[f], x[f], lg);
+      lg += c;
+      float p = 1.0f / (1.0f + expf(-lg));
+      p = fminf(fmaxf(p, ds.p3), 1.0f - ds.p3);
+      p = fminf(fmaxf(p, eps), 1.0f - eps);
+      const float l2 = logf(p) - log1pf(-p);
+      // binary_cross_entropy_with_logits = (1-y)*l + log(1+exp(-|l|)) + max(-l,0)
+      const float y = ds.aux1[n];
+      ll -= (1.0f - y) * l2 + (fmaxf(-l2, 0.0f) + log1pf(expf(-fabsf(l2))));
+    }
+    out = ll + prior;
+  }
+  if (ds.clip > 0.0f) out = clampf(out, ds.clip);
+  return out;
+}
+
+__device__ void dist_score_row(const DistEvalArgs& a, const float* x, float* sc) {
+  const int d = a.d;
+  const DistDev& ds = a.ds;
+  if (ds.kind == SDENG_DIST_GMM_DIAG) {  // distr/gauss.py:97-107
+    float m_run = -INFINITY, l_run = 0.0f;
+    for (int f = 0; f < d; ++f) sc[f] = 0.0f;
+    for (int c = 0; c < ds.k; ++c) {
+      const float* tm = ds.tab + static_cast<size_t>(c) * 2 * a.dpad;
+      const float* tv = tm + a.dpad;
+      float part = 0.0f;
+      for (int f = 0; f < d; ++f) {
+        const float dl = x[f] - tm[f];
+        part = __builtin_fmaf(dl * dl, tv[f], part);
+      }
+      float lp = ((-0.5f * part) - ds.p0) - ds.consts[4 * c + 0];
+      lp = ds.consts[4 * c + 1] + lp;
+      const float m_new = fmaxf(m_run, lp);
+      const float so = expf(m_run - m_new), pk = expf(lp - m_new);
+      l_run = l_run * so + pk;
+      m_run = m_new;
+      for (int f = 0; f < d; ++f) sc[f] = __builtin_fmaf(pk, (tm[f] - x[f]) * tv[f], sc[f] * so);
+    }
+    const float inv = 1.0f / l_run;
+    for (int f = 0; f < d; ++f) sc[f] *= inv;
+  } else if (ds.kind == SDENG_DIST_GAUSS_DIAG) {  // distr/gauss.py:124-126
+    for (int f = 0; f < d; ++f) sc[f] = -((x[f] - ds.tab[f]) * ds.tab[a.dpad + f]);
+  } else if (ds.kind == SDENG_DIST_ISO_GAUSS) {  // distr/gauss.py:764-766
+    for (int f = 0; f < d; ++f) sc[f] = (ds.p0 - x[f]) / (ds.p1 * ds.p1);
+  } else if (ds.kind == SDENG_DIST_PHI4) {  // distr/phi_four.py:81-96
+    const float coef = ds.p0 * static_cast<float>(d);
+    for (int f = 0; f < d; ++f) {
+      const float xv = x[f];
+      const float xl = f > 0 ? x[f - 1] : 0.0f, xr = f < d - 1 ? x[f + 1] : 0.0f;
+      float g = (ds.p1 - xv * (1.0f - xv * xv)) / coef;
+      g = g + coef * ((2.0f * xv - xr) - xl);
+      sc[f] = (-ds.p2) * g;
+    }
+  } else if (ds.kind == SDENG_DIST_GAUSS_FULL) {  // distr/gauss.py:129-135; scale ptr in tab = precision [d,d]
+    for (int i = 0; i < d; ++i) {
+      float acc = 0.0f;
+      const float* Pi = ds.tab + static_cast<size_t>(i) * d;
+      for (int j = 0; j < d; ++j) acc = __builtin_fmaf(Pi[j], x[j] - ds.aux0[j], acc);
+      sc[i] = -acc;
+    }
+  } else if (ds.kind == SDENG_DIST_LOGREG) {
+    // the reference differentiates posterior_log_prob by autograd (distr/base.py:146-154); closed form of that
+    // gradient through sigmoid -> clip(thr) -> clamp(eps) -> logit -> BCE-with-logits
+    const int dw = d - 1;
+    const float c = x[dw];
+    const float eps = 1.1920928955078125e-07f;
+    for (int f = 0; f < dw; ++f) sc[f] = -x[f] / (ds.p0 * ds.p0);
+    float gc = -(c - ds.p1) / (ds.p2 * ds.p2);
+    for (int n = 0; n < ds.k; ++n) {
+      const float* Xn = ds.aux0 + static_cast<size_t>(n) * dw;
+      float lg = 0.0f;
+      for (int f = 0; f < dw; ++f) lg = __builtin_fmaf(Xn[f], x[f], lg);
+      lg += c;
+      const float p = 1.0f / (1.0f + expf(-lg));
+      const float pc = fminf(fmaxf(p, ds.p3), 1.0f - ds.p3);
+      const float pcc = fminf(fmaxf(pc, eps), 1.0f - eps);
+      const bool pass = (p >= ds.p3) && (p <= 1.0f - ds.p3) && (pc >= eps) && (pc <= 1.0f - eps);
+      const float l2 = logf(pcc) - log1pf(-pcc);
+      const float sg = 1.0f / (1.0f + expf(-l2));
+      float r = (ds.aux1[n] - sg) * (1.0f / pcc + 1.0f / (1.0f - pcc)) * (p * (1.0f - p));
+      r = pass ? r : 0.0f;
+      for (int f = 0; f < dw; ++f) sc[f] = __builtin_fmaf(r, Xn[f], sc[f]);
+      gc += r;
+    }
+    sc[dw] = gc;
+  }
+}
+
+__global__ void k_dist_eval(DistEvalArgs a) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.B) return;
+  const float* x = a.x + static_cast<size_t>(row) * a.d;
+  if (a.logp_out) a.logp_out[row] = dist_logp_row(a, x);
+  if (a.score_out) dist_score_row(a, x, a.score_out + static_cast<size_t>(row) * a.d);
+}
+
+// terminal cost, in place on rnd (losses/oc.py:290: rnd += ref_logp(x) - target_logp(x); :973: rnd -= target_logp(x))
+__global__ void k_terminal(TerminalArgs a) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.B) return;
+  const float* x = a.x + static_cast<size_t>(row) * a.d;
+  float term = 0.0f;
+  if (a.use_ref) {
+    DistEvalArgs e;
+    e.ds = a.ref; e.B = a.B; e.d = a.d; e.dpad = a.dpad;
+    term = dist_logp_row(e, x);
+  }
+  if (a.use_target) {
+    DistEvalArgs e;
+    e.ds = a.target; e.B = a.B; e.d = a.d; e.dpad = a.dpad;
+    term = term - dist_logp_row(e, x);
+  }
+  a.rnd[row] += term;
+}
+
+// ------------------------------------------------------------------------------------------------
+// estimators (losses/oc.py:150-161; eval/metrics.py:135-140).  Two passes: block partials, then combine.
+// ------------------------------------------------------------------------------------------------
+__device__ inline float block_reduce(float v, float* sh, bool is_max) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(v, o, 64);
+    v = is_max ? fmaxf(v, t) : v + t;
+  }
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < (blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  __syncthreads();
+  return r;
+}
+
+// partials[b] = (max(-rnd), sum(-rnd), sum rnd^2 shifted, count) per block; pass 2 combines
+__global__ void __launch_bounds__(256) k_logz_partial(const float* rnd, long long B, float* partials) {
+  __shared__ float sh[4];
+  float mx = -INFINITY, s1 = 0.0f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < B; i += gridDim.x * 256ll) {
+    const float v = -rnd[i];
+    mx = fmaxf(mx, v);
+    s1 += v;
+  }
+  mx = block_reduce(mx, sh, true);
+  s1 = block_reduce(s1, sh, false);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x + 0] = mx;
+    partials[2 * blockIdx.x + 1] = s1;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_logz_partial2(const float* rnd, long long B, const float* partials, int nb,
+                                                      float* partials2) {
+  __shared__ float sh[4];
+  float mx = -INFINITY, s1 = 0.0f;
+  for (int i = 0; i < nb; ++i) {
+    mx = fmaxf(mx, partials[2 * i]);
+    s1 += partials[2 * i + 1];
+  }
+  const float mean = s1 / static_cast<float>(B);  // mean of -rnd
+  float se = 0.0f, se2 = 0.0f, sv = 0.0f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < B; i += gridDim.x * 256ll) {
+    const float v = -rnd[i];
+    const float ex = expf(v - mx);
+    se += ex;
+    se2 = __builtin_fmaf(ex, ex, se2);
+    const float dv = v - mean;
+    sv = __builtin_fmaf(dv, dv, sv);
+  }
+  se = block_reduce(se, sh, false);
+  se2 = block_reduce(se2, sh, false);
+  sv = block_reduce(sv, sh, false);
+  if (threadIdx.x == 0) {
+    partials2[3 * blockIdx.x + 0] = se;
+    partials2[3 * blockIdx.x + 1] = se2;
+    partials2[3 * blockIdx.x + 2] = sv;
+  }
+}
+
+__global__ void k_logz_final(const float* partials, const float* partials2, int nb, long long B, float* stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float mx = -INFINITY, s1 = 0.0f, se = 0.0f, se2 = 0.0f, sv = 0.0f;
+  for (int i = 0; i < nb; ++i) {
+    mx = fmaxf(mx, partials[2 * i]);
+    s1 += partials[2 * i + 1];
+    se += partials2[3 * i];
+    se2 += partials2[3 * i + 1];
+    sv += partials2[3 * i + 2];
+  }
+  const float fB = static_cast<float>(B);
+  stats[0] = s1 / fB;
+  stats[1] = (mx + logf(se)) - logf(fB);
+  stats[2] = B > 1 ? sv / (fB - 1.0f) : 0.0f;
+  stats[3] = (se * se) / se2 / fB;
+  stats[4] = mx;
+  stats[5] = se;
+  stats[6] = se2;
+  stats[7] = s1;
+}
+
+__global__ void k_softmax_weights(const float* rnd, long long B, const float* stats, float* w) {
+  const long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  if (i >= B) return;
+  w[i] = expf((-rnd[i]) - stats[4]) / stats[5];
+}
+
+__global__ void k_philox(unsigned seed_lo, unsigned seed_hi, int step, long long particle0, int B, int d, unsigned stream_id,
+                         float* out) {
+  const int nj = (d + 3) / 4;
+  const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  if (idx >= static_cast<long long>(B) * nj) return;
+  const int row = static_cast<int>(idx / nj), jb = static_cast<int>(idx % nj);
+  const f32x4 z = philox_normal4(static_cast<uint32_t>(particle0 + row), static_cast<uint32_t>(step), static_cast<uint32_t>(jb),
+                                 stream_id, seed_lo, seed_hi);
+  for (int e = 0; e < 4; ++e)
+    if (4 * jb + e < d) out[static_cast<size_t>(row) * d + 4 * jb + e] = z[e];
+}
+
+// ---- host-side launch wrappers -------------------------------------------------------------------
+int sd_launch_pack(const PackArgs& a, hipStream_t s) {
+  const int total = sd_lds_floats(a.DT);
+  hipLaunchKernelGGL(k_pack_mlp, dim3((total + 255) / 256), dim3(256), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_time_embed(const TimeEmbedArgs& a, int N, hipStream_t s) {
+  hipLaunchKernelGGL(k_time_embed, dim3(N), dim3(64), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_ref_tables(const RefTabArgs& a, int N, hipStream_t s) {
+  hipLaunchKernelGGL(k_ref_tables, dim3(N * a.K), dim3(128), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_dist_tables(const DistTabArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_dist_tables, dim3(a.K), dim3(128), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_dist_eval(const DistEvalArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_dist_eval, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_terminal(const TerminalArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_terminal, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_logz(const float* rnd, long long B, float* stats, float* weights, float* scratch, hipStream_t s) {
+  int nb = static_cast<int>((B + 256 * 8 - 1) / (256 * 8));
+  if (nb > SD_LOGZ_MAX_BLOCKS) nb = SD_LOGZ_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  float* p1 = scratch;
+  float* p2 = scratch + 2 * SD_LOGZ_MAX_BLOCKS;
+  hipLaunchKernelGGL(k_logz_partial, dim3(nb), dim3(256), 0, s, rnd, B, p1);
+  hipLaunchKernelGGL(k_logz_partial2, dim3(nb), dim3(256), 0, s, rnd, B, p1, nb, p2);
+  hipLaunchKernelGGL(k_logz_final, dim3(1), dim3(64), 0, s, p1, p2, nb, B, stats);
+  if (weights) hipLaunchKernelGGL(k_softmax_weights, dim3(static_cast<unsigned>((B + 255) / 256)), dim3(256), 0, s, rnd, B, stats, weights);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_philox(unsigned lo, unsigned hi, int step, long long p0, int B, int d, unsigned stream_id, float* out, hipStream_t s) {
+  const long long n = static_cast<long long>(B) * ((d + 3) / 4);
+  hipLaunchKernelGGL(k_philox, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, lo, hi, step, p0, B, d, stream_id, out);
+  return static_cast<int>(hipGetLastError());
+}

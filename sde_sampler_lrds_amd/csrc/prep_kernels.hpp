@@ -1,0 +1,62 @@
+// Argument blocks and host launchers of the small kernels in prep_kernels.hip.
+#pragma once
+#include "sim_common.hpp"
+#include "../../include/sdeng.h"
+
+#define SD_LOGZ_MAX_BLOCKS 1024
+
+struct PackArgs {
+  int DT, d;
+  const float *w_in, *b_in, *w_h1, *b_h1, *w_h2, *b_h2, *w_out, *b_out;
+  float* out;
+};
+
+struct TimeEmbedArgs {
+  sdeng_time_embed te;
+  const float* coef;  // [N][16]; time = coef[k][col]
+  int col;
+  int t_direct;       // 1: use t_value for every block (single-time evaluation)
+  float t_value;
+  float clip;         // <= 0: none
+  float* out;         // [N][dim_out]
+};
+
+struct RefTabArgs {
+  int K, d, dpad;
+  const float* coef;
+  const float *means, *vars, *weights;
+  float* tab;     // [N][K][2][dpad]
+  float* consts;  // [N][K][2]
+};
+
+struct DistTabArgs {
+  int K, d, dpad;
+  const float *loc, *scale, *weights;  // weights nullptr: single Gaussian
+  float* tab;     // [K][2][dpad]
+  float* consts;  // [K][4]
+};
+
+struct DistEvalArgs {
+  DistDev ds;
+  int B, d, dpad;
+  const float* x;
+  float* logp_out;
+  float* score_out;
+};
+
+struct TerminalArgs {
+  DistDev ref, target;
+  int use_ref, use_target;
+  int B, d, dpad;
+  const float* x;
+  float* rnd;
+};
+
+int sd_launch_pack(const PackArgs& a, hipStream_t s);
+int sd_launch_time_embed(const TimeEmbedArgs& a, int N, hipStream_t s);
+int sd_launch_ref_tables(const RefTabArgs& a, int N, hipStream_t s);
+int sd_launch_dist_tables(const DistTabArgs& a, hipStream_t s);
+int sd_launch_dist_eval(const DistEvalArgs& a, hipStream_t s);
+int sd_launch_terminal(const TerminalArgs& a, hipStream_t s);
+int sd_launch_logz(const float* rnd, long long B, float* stats, float* weights, float* scratch, hipStream_t s);
+int sd_launch_philox(unsigned lo, unsigned hi, int step, long long p0, int B, int d, unsigned stream_id, float* out, hipStream_t s);

@@ -1,0 +1,377 @@
+// extern "C" entry points of libsdeng.so (see include/sdeng.h): descriptor validation, workspace
+// carving, preparation kernels, dispatch to the simulate-kernel instantiations.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/sdeng.h"
+#include "prep_kernels.hpp"
+#include "sim_common.hpp"
+
+enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2 };
+enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
+
+typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
+#define SD_DECLARE_SIM(DT, REF, SC, FORM) int sd_launch_sim_##DT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s);
+#define SD_DECLARE_CTRL(DT, SC) int sd_launch_ctrl_##DT##_##SC(const SimArgs& a, int grid, hipStream_t s);
+#define SD_FOR_FORM(M, DT, REF, SC) M(DT, REF, SC, 0) M(DT, REF, SC, 1)
+#define SD_FOR_SC(M, DT, REF) SD_FOR_FORM(M, DT, REF, 0) SD_FOR_FORM(M, DT, REF, 1) SD_FOR_FORM(M, DT, REF, 2)
+#define SD_FOR_REF(M, DT) SD_FOR_SC(M, DT, 0) SD_FOR_SC(M, DT, 1) SD_FOR_SC(M, DT, 2)
+SD_FOR_REF(SD_DECLARE_SIM, 1)
+SD_FOR_REF(SD_DECLARE_SIM, 2)
+SD_FOR_REF(SD_DECLARE_SIM, 4)
+#define SD_CTRL_ROW(M, DT) M(DT, 0) M(DT, 1) M(DT, 2)
+SD_CTRL_ROW(SD_DECLARE_CTRL, 1)
+SD_CTRL_ROW(SD_DECLARE_CTRL, 2)
+SD_CTRL_ROW(SD_DECLARE_CTRL, 4)
+
+#define SD_ENTRY(DT, REF, SC, FORM) sd_launch_sim_##DT##_##REF##_##SC##_##FORM,
+static const sim_launch_fn kSimTable[3][3][3][2] = {
+#define SD_TAB_FORM(DT, REF, SC) {SD_ENTRY(DT, REF, SC, 0) SD_ENTRY(DT, REF, SC, 1)},
+#define SD_TAB_SC(DT, REF) {SD_TAB_FORM(DT, REF, 0) SD_TAB_FORM(DT, REF, 1) SD_TAB_FORM(DT, REF, 2)},
+#define SD_TAB_REF(DT) {SD_TAB_SC(DT, 0) SD_TAB_SC(DT, 1) SD_TAB_SC(DT, 2)},
+    SD_TAB_REF(1) SD_TAB_REF(2) SD_TAB_REF(4)};
+#define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
+static const sim_launch_fn kCtrlTable[3][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}};
+
+// ---- error string ------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define SD_HIP(expr)                                                                  \
+  do {                                                                                \
+    int e_ = (expr);                                                                  \
+    if (e_ != 0) return fail(SDENG_E_HIP, "%s failed: %s", #expr, hipGetErrorString(static_cast<hipError_t>(e_))); \
+  } while (0)
+
+extern "C" int sdeng_abi_version(void) { return SDENG_ABI_VERSION; }
+extern "C" const char* sdeng_last_error(void) { return g_err; }
+
+// ---- workspace layout ----------------------------------------------------------------------------
+static inline size_t align64(size_t n_floats) { return (n_floats + 63) & ~static_cast<size_t>(63); }
+static int tiles_of(int d) { return d <= 32 ? 1 : (d <= 64 ? 2 : 4); }
+static int dt_index(int DT) { return DT == 1 ? 0 : (DT == 2 ? 1 : 2); }
+
+static size_t dist_floats(const sdeng_dist& ds, int dpad) {
+  if (ds.kind == SDENG_DIST_GMM_DIAG) return align64(static_cast<size_t>(ds.k) * 2 * dpad) + align64(static_cast<size_t>(ds.k) * 4);
+  if (ds.kind == SDENG_DIST_GAUSS_DIAG) return align64(2 * dpad) + align64(4);
+  return 0;
+}
+
+struct Layout {
+  size_t wpack, temb, stheta, ref_tab, ref_consts, target, ref_dist, prior, rnd_init, trash, logz, total;
+};
+
+static bool make_layout(const sdeng_desc* d, Layout& L) {
+  if (!d || d->d < 1 || d->d > 128 || d->N < 0 || d->B < 0) return false;
+  const int DT = tiles_of(d->d), dpad = 32 * DT;
+  size_t o = 0;
+  L.wpack = o; o += align64(sd_lds_floats(DT));
+  L.temb = o; o += align64(static_cast<size_t>(d->N > 0 ? d->N : 1) * SD_H);
+  L.stheta = o; o += align64(d->N > 0 ? d->N : 1);
+  const int K = d->ref.kind == SDENG_REF_NONE ? 0 : (d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k);
+  L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * K * 2 * dpad);
+  L.ref_consts = o; o += align64(static_cast<size_t>(d->N) * K * 2);
+  L.target = o; o += dist_floats(d->target, dpad);
+  L.ref_dist = o; o += dist_floats(d->ref_dist, dpad);
+  L.prior = o; o += dist_floats(d->prior, dpad);
+  L.rnd_init = o; o += align64(d->B);
+  L.trash = o; o += align64(SD_THREADS * 4);
+  L.logz = o; o += align64(5 * SD_LOGZ_MAX_BLOCKS);
+  L.total = o;
+  return true;
+}
+
+extern "C" size_t sdeng_workspace_bytes(const sdeng_desc* desc) {
+  Layout L;
+  if (!make_layout(desc, L)) return 0;
+  return L.total * sizeof(float);
+}
+
+// ---- distribution descriptor -> device view (+ table kernels) -------------------------------------
+static int build_dist(const sdeng_dist& in, int d, int dpad, float* ws, DistDev& out, hipStream_t s) {
+  memset(&out, 0, sizeof(out));
+  out.kind = in.kind;
+  out.k = in.k;
+  out.p0 = in.p0; out.p1 = in.p1; out.p2 = in.p2; out.p3 = in.p3;
+  out.clip = in.clip;
+  switch (in.kind) {
+    case SDENG_DIST_NONE:
+      return 0;
+    case SDENG_DIST_GMM_DIAG:
+    case SDENG_DIST_GAUSS_DIAG: {
+      const int K = in.kind == SDENG_DIST_GMM_DIAG ? in.k : 1;
+      if (K < 1 || !in.loc || !in.scale || (in.kind == SDENG_DIST_GMM_DIAG && !in.w))
+        return fail(SDENG_E_INVALID, "diagonal Gaussian/mixture needs loc, scale%s", in.kind == SDENG_DIST_GMM_DIAG ? ", w and k >= 1" : "");
+      DistTabArgs t;
+      t.K = K; t.d = d; t.dpad = dpad;
+      t.loc = in.loc; t.scale = in.scale; t.weights = in.kind == SDENG_DIST_GMM_DIAG ? in.w : nullptr;
+      t.tab = ws; t.consts = ws + align64(static_cast<size_t>(K) * 2 * dpad);
+      SD_HIP(sd_launch_dist_tables(t, s));
+      out.k = K;
+      out.tab = t.tab; out.consts = t.consts;
+      out.p0 = static_cast<float>(0.5 * d * std::log(2.0 * M_PI));  // distr/gauss.py:71
+      return 0;
+    }
+    case SDENG_DIST_ISO_GAUSS:
+    case SDENG_DIST_PHI4:
+      return 0;
+    case SDENG_DIST_GAUSS_FULL:
+      if (!in.loc || !in.scale || !in.w) return fail(SDENG_E_INVALID, "GAUSS_FULL needs loc, precision, inverse Cholesky factor");
+      out.aux0 = in.loc; out.tab = in.scale; out.aux1 = in.w;
+      return 0;
+    case SDENG_DIST_LOGREG:
+      if (!in.loc || !in.scale || in.k < 1) return fail(SDENG_E_INVALID, "LOGREG needs X, y and k >= 1 rows");
+      out.aux0 = in.loc; out.aux1 = in.scale;
+      return 0;
+    default:
+      return fail(SDENG_E_UNSUPPORTED, "unknown distribution kind %d", in.kind);
+  }
+}
+
+static int check_net(const sdeng_net& n) {
+  if (!n.w_in || !n.b_in || !n.w_h1 || !n.b_h1 || !n.w_h2 || !n.b_h2 || !n.w_out || !n.b_out)
+    return fail(SDENG_E_INVALID, "drift net: null weight pointer");
+  const sdeng_time_embed& te = n.t_embed;
+  if (!te.coeff || !te.phase || te.n_hidden != 1 || te.dim_out != SD_H || !te.w[0] || !te.b[0] || !te.w_out || !te.b_out)
+    return fail(SDENG_E_UNSUPPORTED, "drift net time embedding must be TimeEmbed(num_layers=2, channels=64)");
+  if (n.ctrl_kind != SDENG_CTRL_CLIPPED) {
+    const sdeng_time_embed& sm = n.score_model;
+    if (sm.n_hidden > 0) {
+      if (sm.n_hidden > 4 || sm.dim_out != 1 || !sm.coeff || !sm.phase || !sm.w_out || !sm.b_out)
+        return fail(SDENG_E_UNSUPPORTED, "score_model must be TimeEmbed(dim_out=1, num_layers<=5)");
+      for (int i = 0; i < sm.n_hidden; ++i)
+        if (!sm.w[i] || !sm.b[i]) return fail(SDENG_E_INVALID, "score_model: null weight pointer");
+    }
+  }
+  return 0;
+}
+
+// common preparation for simulate / ctrl_forward: pack weights, time embeddings, target tables.
+static int prepare_net(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s, int n_times,
+                       bool t_direct, float t_value) {
+  int rc = check_net(d->net);
+  if (rc) return rc;
+  PackArgs pk;
+  pk.DT = DT; pk.d = d->d;
+  pk.w_in = d->net.w_in; pk.b_in = d->net.b_in; pk.w_h1 = d->net.w_h1; pk.b_h1 = d->net.b_h1;
+  pk.w_h2 = d->net.w_h2; pk.b_h2 = d->net.b_h2; pk.w_out = d->net.w_out; pk.b_out = d->net.b_out;
+  pk.out = ws + L.wpack;
+  SD_HIP(sd_launch_pack(pk, s));
+  a.wpack = pk.out;
+  if (n_times > 0) {
+    TimeEmbedArgs te;
+    te.te = d->net.t_embed; te.coef = d->coef; te.col = 0; te.t_direct = t_direct; te.t_value = t_value; te.clip = 0.0f;
+    te.out = ws + L.temb;
+    SD_HIP(sd_launch_time_embed(te, n_times, s));
+    a.stheta = nullptr;
+    if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && d->net.score_model.n_hidden > 0) {
+      TimeEmbedArgs sm;
+      sm.te = d->net.score_model; sm.coef = d->coef; sm.col = 0; sm.t_direct = t_direct; sm.t_value = t_value;
+      sm.clip = d->net.clip_model;  // reparam.py:102-110 clips the score model with clip_model
+      sm.out = ws + L.stheta;
+      SD_HIP(sd_launch_time_embed(sm, n_times, s));
+      a.stheta = sm.out;
+    }
+  }
+  a.temb = ws + L.temb;
+  a.ctrl_kind = d->net.ctrl_kind;
+  a.clip_model = d->net.clip_model;
+  a.clip_score = d->net.clip_score;
+  a.scale_score = d->net.scale_score;
+  return 0;
+}
+
+static int score_kind(const sdeng_desc* d, int& sc) {
+  sc = SC_NONE;
+  if (d->net.ctrl_kind == SDENG_CTRL_CLIPPED) return 0;
+  if (d->net.ctrl_kind != SDENG_CTRL_SCORE && d->net.ctrl_kind != SDENG_CTRL_LERP)
+    return fail(SDENG_E_UNSUPPORTED, "unknown ctrl_kind %d", d->net.ctrl_kind);
+  if (d->target.kind == SDENG_DIST_GMM_DIAG) sc = SC_GMM;
+  else if (d->target.kind == SDENG_DIST_PHI4) sc = SC_PHI4;
+  else return fail(SDENG_E_UNSUPPORTED, "ScoreCtrl/LerpCtrl: no in-loop score kernel for target kind %d", d->target.kind);
+  if (d->net.ctrl_kind == SDENG_CTRL_LERP && d->prior.kind != SDENG_DIST_ISO_GAUSS)
+    return fail(SDENG_E_UNSUPPORTED, "LerpCtrl needs an IsotropicGauss prior (kind %d given)", d->prior.kind);
+  return 0;
+}
+
+static int grid_for(int ntiles) {
+  int g = (ntiles + SD_WAVES - 1) / SD_WAVES;
+  if (g > 256) g = 256;  // one persistent workgroup per CU (LDS image + 2 waves/SIMD fill a CU)
+  return g < 1 ? 1 : g;
+}
+
+extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!d) return fail(SDENG_E_INVALID, "null descriptor");
+  if (d->abi_version != SDENG_ABI_VERSION) return fail(SDENG_E_INVALID, "ABI version %d, library has %d", d->abi_version, SDENG_ABI_VERSION);
+  Layout L;
+  if (!make_layout(d, L)) return fail(SDENG_E_INVALID, "bad sizes: B=%d d=%d N=%d (need 1 <= d <= 128)", d->B, d->d, d->N);
+  if (d->B == 0) return 0;
+  if (!d->coef || !d->x_in || !d->x_out || !d->rnd_out) return fail(SDENG_E_INVALID, "null coef/x_in/x_out/rnd_out");
+  if (!d->workspace || d->workspace_bytes < L.total * sizeof(float))
+    return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, L.total * sizeof(float));
+  if (static_cast<long long>(d->B) * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "B*d >= 2^31");
+  if (d->form == SDENG_FORM_CMCD) return fail(SDENG_E_UNSUPPORTED, "FORM_CMCD: kernel not built in this version");
+  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM) return fail(SDENG_E_INVALID, "unknown form %d", d->form);
+  const int DT = tiles_of(d->d), dpad = 32 * DT;
+  float* ws = static_cast<float*>(d->workspace);
+
+  SimArgs a;
+  memset(&a, 0, sizeof(a));
+  a.form = d->form; a.flags = d->flags;
+  a.B = d->B; a.d = d->d; a.N = d->N;
+  a.particle0 = d->particle0;
+  a.seed_lo = static_cast<unsigned>(d->seed & 0xFFFFFFFFull);
+  a.seed_hi = static_cast<unsigned>(d->seed >> 32);
+  a.coef = d->coef; a.x_in = d->x_in; a.x_out = d->x_out; a.rnd_out = d->rnd_out;
+  a.xs_out = d->xs_out; a.noise_in = d->noise_in;
+  a.trash = ws + L.trash;
+  a.ntiles = (d->B + 31) / 32;
+
+  int rc = prepare_net(d, L, ws, DT, a, s, d->N, false, 0.0f);
+  if (rc) return rc;
+  int sc;
+  rc = score_kind(d, sc);
+  if (rc) return rc;
+
+  // reference drift tables
+  int rf = RF_NONE;
+  if (d->ref.kind == SDENG_REF_GAUSS_DIAG || d->ref.kind == SDENG_REF_GMM_DIAG) {
+    rf = d->ref.kind == SDENG_REF_GAUSS_DIAG ? RF_GAUSS : RF_GMM;
+    const int K = rf == RF_GAUSS ? 1 : d->ref.k;
+    if (K < 1 || !d->ref.means_init || !d->ref.vars_init) return fail(SDENG_E_INVALID, "reference: null means/vars or k < 1");
+    if (d->N > 0) {
+      RefTabArgs r;
+      r.K = K; r.d = d->d; r.dpad = dpad; r.coef = d->coef;
+      r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = rf == RF_GMM ? d->ref.weights : nullptr;
+      r.tab = ws + L.ref_tab; r.consts = ws + L.ref_consts;
+      SD_HIP(sd_launch_ref_tables(r, d->N, s));
+    }
+    a.ref_k = K;
+    a.ref_tab = ws + L.ref_tab; a.ref_consts = ws + L.ref_consts;
+    a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
+  } else if (d->ref.kind != SDENG_REF_NONE) {
+    return fail(SDENG_E_UNSUPPORTED, "reference kind %d", d->ref.kind);
+  }
+
+  DistDev target, ref_dist, prior;
+  rc = build_dist(d->target, d->d, dpad, ws + L.target, target, s);
+  if (rc) return rc;
+  rc = build_dist(d->ref_dist, d->d, dpad, ws + L.ref_dist, ref_dist, s);
+  if (rc) return rc;
+  rc = build_dist(d->prior, d->d, dpad, ws + L.prior, prior, s);
+  if (rc) return rc;
+  a.target = target;
+  a.prior = prior;
+
+  // initial cost
+  if (d->flags & SDENG_FLAG_INIT_LOGP) {
+    if (prior.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_INIT_LOGP without a prior");
+    DistEvalArgs e;
+    e.ds = prior; e.B = d->B; e.d = d->d; e.dpad = dpad; e.x = d->x_in; e.logp_out = ws + L.rnd_init; e.score_out = nullptr;
+    SD_HIP(sd_launch_dist_eval(e, s));
+    a.rnd_init = ws + L.rnd_init;
+  }
+
+  sim_launch_fn fn = kSimTable[dt_index(DT)][rf][sc][d->form];
+  SD_HIP(fn(a, grid_for(a.ntiles), s));
+
+  // terminal cost
+  const bool tr = d->flags & SDENG_FLAG_TERM_REF, tt = d->flags & SDENG_FLAG_TERM_TARGET;
+  if (tr || tt) {
+    if (tr && ref_dist.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_TERM_REF without ref_dist");
+    if (tt && target.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_TERM_TARGET without target");
+    TerminalArgs t;
+    t.ref = ref_dist; t.target = target; t.use_ref = tr; t.use_target = tt;
+    t.B = d->B; t.d = d->d; t.dpad = dpad; t.x = d->x_out; t.rnd = d->rnd_out;
+    SD_HIP(sd_launch_terminal(t, s));
+  }
+  return 0;
+}
+
+extern "C" int sdeng_ctrl_forward(const sdeng_desc* d, float t_net, float score_gain, float lerp_w, const float* x, float* u_out,
+                                  void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!d || !x || !u_out) return fail(SDENG_E_INVALID, "null argument");
+  Layout L;
+  if (!make_layout(d, L)) return fail(SDENG_E_INVALID, "bad sizes");
+  if (!d->workspace || d->workspace_bytes < L.total * sizeof(float)) return fail(SDENG_E_WORKSPACE, "workspace too small");
+  if (d->B == 0) return 0;
+  const int DT = tiles_of(d->d), dpad = 32 * DT;
+  float* ws = static_cast<float*>(d->workspace);
+  SimArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = d->B; a.d = d->d; a.N = 1;
+  a.x_in = x; a.x_out = u_out;
+  a.trash = ws + L.trash;
+  a.ntiles = (d->B + 31) / 32;
+  int rc = prepare_net(d, L, ws, DT, a, s, 1, true, t_net);
+  if (rc) return rc;
+  int sc;
+  rc = score_kind(d, sc);
+  if (rc) return rc;
+  DistDev target, prior;
+  rc = build_dist(d->target, d->d, dpad, ws + L.target, target, s);
+  if (rc) return rc;
+  rc = build_dist(d->prior, d->d, dpad, ws + L.prior, prior, s);
+  if (rc) return rc;
+  a.target = target; a.prior = prior;
+  // one-row coefficient table for (score_gain, lerp_w), kept in the (unused) reference-consts slot
+  float host_coef[SDENG_NCOEF] = {0};
+  host_coef[0] = t_net; host_coef[7] = score_gain; host_coef[8] = lerp_w;
+  float* dev_coef = ws + L.logz;
+  SD_HIP(hipMemcpyAsync(dev_coef, host_coef, sizeof(host_coef), hipMemcpyHostToDevice, s));
+  a.coef = dev_coef;
+  SD_HIP(kCtrlTable[dt_index(DT)][sc](a, grid_for(a.ntiles), s));
+  return 0;
+}
+
+extern "C" int sdeng_dist_eval(const sdeng_dist* dist, int32_t B, int32_t d, const float* x, float* logp_out, float* score_out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!dist || !x || d < 1 || B < 0) return fail(SDENG_E_INVALID, "bad argument");
+  if (B == 0) return 0;
+  const int dpad = 32 * ((d + 31) / 32);
+  const size_t need = dist_floats(*dist, dpad) * sizeof(float);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", workspace_bytes, need);
+  DistDev dd;
+  int rc = build_dist(*dist, d, dpad, static_cast<float*>(workspace), dd, s);
+  if (rc) return rc;
+  DistEvalArgs e;
+  e.ds = dd; e.B = B; e.d = d; e.dpad = dpad; e.x = x; e.logp_out = logp_out; e.score_out = score_out;
+  SD_HIP(sd_launch_dist_eval(e, s));
+  return 0;
+}
+
+extern "C" size_t sdeng_dist_workspace_bytes(const sdeng_dist* dist, int32_t d) {
+  if (!dist || d < 1) return 0;
+  return dist_floats(*dist, 32 * ((d + 31) / 32)) * sizeof(float);
+}
+
+extern "C" size_t sdeng_logz_workspace_bytes(void) { return 5 * SD_LOGZ_MAX_BLOCKS * sizeof(float); }
+
+extern "C" int sdeng_logz(const float* rnd, int64_t B, float* stats, float* weights_out, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!rnd || !stats || B < 1) return fail(SDENG_E_INVALID, "bad argument");
+  if (!workspace || workspace_bytes < sdeng_logz_workspace_bytes()) return fail(SDENG_E_WORKSPACE, "logz workspace too small");
+  SD_HIP(sd_launch_logz(rnd, B, stats, weights_out, static_cast<float*>(workspace), static_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int sdeng_philox_normal(uint64_t seed, int32_t step, int64_t particle0, int32_t B, int32_t d, uint32_t stream_id, float* out,
+                                   void* stream) {
+  if (!out || B < 0 || d < 1) return fail(SDENG_E_INVALID, "bad argument");
+  if (B == 0) return 0;
+  SD_HIP(sd_launch_philox(static_cast<unsigned>(seed & 0xFFFFFFFFull), static_cast<unsigned>(seed >> 32), step, particle0, B, d, stream_id,
+                          out, static_cast<hipStream_t>(stream)));
+  return 0;
+}

@@ -1,0 +1,232 @@
+// The persistent whole-trajectory simulate kernel (FORM_LIN / FORM_EM) for gfx950.
+//
+// One launch runs all N steps.  A wave keeps its 32 particles' state x[d] in registers for the whole
+// trajectory; HBM sees x once in and once out ((2d+1)*4 bytes per particle per TRAJECTORY).  Per step a
+// wave does: drift net (FP32 MFMA chain, weights in LDS), optional target score inside the control
+// (ScoreCtrl/LerpCtrl), optional reference score (noised Gaussian / mixture, tables per step from L2),
+// noise (Philox in-register or injected), the integrator update and the log-RND accumulation
+// (one cross-half shuffle per reduction).  No barrier inside the step loop: the two waves sharing a SIMD
+// drift apart so that one's MFMA phase overlaps the other's VALU phase.
+#pragma once
+#include "sim_device.hpp"
+
+enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2 };
+enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
+
+// score part of the generative control for one feature tile (added to clip(net)):
+//   ScoreCtrl (models/reparam.py:112-117):  scale*clip(score_pi(x)) * s_theta(t)
+//   LerpCtrl  (models/reparam.py:166-199):  g(t) * (scale*clip(lerp(score_prior, score_pi, t/T)) * s_theta(t))
+SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, float score_gain, float lerp_w,
+                                bool in_range) {
+  const bool lerp = a.ctrl_kind == SDENG_CTRL_LERP;
+  if (lerp) {  // torch.lerp(prior_score, target_score, w); IsotropicGauss.score = (loc - x)/scale^2
+    const float ps = (a.prior.p0 - xv) / (a.prior.p1 * a.prior.p1);
+    const float df = sv - ps;
+    sv = (lerp_w < 0.5f) ? ps + lerp_w * df : sv - df * (1.0f - lerp_w);
+  }
+  if (a.clip_score > 0.0f) sv = clampf(sv, a.clip_score);
+  float v = a.scale_score * sv;
+  v = v * st;
+  v = lerp ? score_gain * v : v;
+  return in_range ? v : 0.0f;
+}
+
+template <int DT, int REF, int SC, int FORM>
+__global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const SimArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int dpad = 32 * DT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {  // packed drift-net image -> LDS, once per workgroup
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    const int n4 = sd_lds_floats(DT) / 4;
+    for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int p = lane & 31, h = lane >> 5;
+  constexpr bool lin = FORM == SDENG_FORM_LIN;
+  const bool full_d = a.d == dpad;
+  float* trash = a.trash + tid * 4;
+
+  for (int tile = blockIdx.x * SD_WAVES + wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {
+    const uint32_t row = static_cast<uint32_t>(tile) * 32u + p;
+    const bool live = row < static_cast<uint32_t>(a.B);
+    const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
+    f32x16 x[DT];
+    load_rows<DT>(a.x_in, row, a.d, live, h, x);
+    // rnd0 = log p_prior(x0) when the loss asks for it (losses/oc.py:695-699, 935-939), from k_dist_eval
+    float rnd = 0.0f;
+    if (a.rnd_init) rnd = (live ? a.rnd_init[row] : 0.0f);
+    if (a.xs_out) store_rows<DT>(a.xs_out, trash, row, a.d, live, h, x);
+
+    for (int k = 0; k < a.N; ++k) {
+      const float* cf = a.coef + static_cast<size_t>(k) * SDENG_NCOEF;
+      const float c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5], c6 = cf[6];
+      const float score_gain = cf[7], lerp_w = cf[8];
+      // `d` re-read through an opaque move every step: keeps the per-element pad masks (f < d) from being
+      // hoisted out of the step loop, where 64 of them would occupy 128 SGPRs and spill
+      int d_dyn = a.d;
+      asm volatile("" : "+s"(d_dyn));
+
+      // ---- drift net up to the last hidden activation (FP32 MFMA chain) ----
+      f32x16 hid[2];
+      mlp_hidden<DT>(x, hid, lds, a.temb + static_cast<size_t>(k) * SD_H, lane);
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- scores at the OLD state: target score inside the control, reference drift ----
+      f32x16 ts[SC != SC_NONE ? DT : 1];
+      if constexpr (SC == SC_GMM) gmm_score<DT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, h, ts);
+      if constexpr (SC == SC_PHI4) phi4_score<DT>(x, a.target, d_dyn, h, ts);
+      f32x16 rs[REF != RF_NONE ? DT : 1];
+      if constexpr (REF == RF_GMM) {  // eq/sdes.py:329-345
+        gmm_score<DT>(x, a.ref_tab + static_cast<size_t>(k) * a.ref_k * 2 * dpad,
+                      a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2, 2, a.ref_k, a.ref_c1, h, rs);
+      }
+      if constexpr (REF == RF_GAUSS) gauss_score<DT>(x, a.ref_tab + static_cast<size_t>(k) * 2 * dpad, h, rs);  // :265-279
+      __builtin_amdgcn_sched_barrier(0);
+      float st = 1.0f;
+      if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[k] : 1.0f;
+
+      // ---- per output tile: out_layer (MFMA) -> clip -> cost -> noise -> integrator -> Ito term ----
+      float su2 = 0.0f, suz = 0.0f;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        f32x16 u = mlp_out_tile<DT>(hid, lds, t, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float uv = u[r];
+          if (a.clip_model > 0.0f) uv = clampf(uv, a.clip_model);
+          if constexpr (SC != SC_NONE)
+            uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * h, d_dyn));
+          u[r] = uv;
+          su2 = __builtin_fmaf(uv, uv, su2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int fb = 32 * t + 8 * q + 4 * h;
+          f32x4 z;
+          if (a.noise_in) {
+            z = load_quad(a.noise_in + static_cast<size_t>(k) * a.B * a.d, row, d_dyn, live, t, q, h);
+          } else {
+            z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(fb >> 2), 0u, a.seed_lo, a.seed_hi);
+            if (!full_d) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) z[e] = feat_lt(t, 4 * q + e, 4 * h, d_dyn) ? z[e] : 0.0f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const float xv = x[t][r], uv = u[r];
+            if constexpr (lin) {  // eq/sdes.py:535-538: ret = c1*x + c2*(ref + u); ret += c3*z
+              float sc = uv;
+              if constexpr (REF != RF_NONE) sc = rs[t][r] + uv;
+              x[t][r] = (c1 * xv + c2 * sc) + c3 * z[e];
+              suz = __builtin_fmaf(uv, z[e], suz);
+            } else {  // losses/oc.py:277-284
+              const float db = z[e] * c5;
+              float f = c1 * xv;
+              if constexpr (REF != RF_NONE) f = f + c3 * rs[t][r];
+              x[t][r] = xv + (f + c2 * uv) * c4 + c2 * db;
+              suz = __builtin_fmaf(uv, db, suz);
+            }
+          }
+        }
+      }
+      // running cost 0.5*omega*|u|^2 (losses/oc.py:493) or 0.5*|u|^2*dt (:274); per-step constant
+      // (TimeReversalLoss: -int drift divergence, :1218-1219); stochastic integral (:284, :499)
+      su2 = half_sum(su2);
+      rnd += lin ? c4 * su2 : (0.5f * su2) * c4;
+      rnd += c6;
+      if (a.flags & SDENG_FLAG_ITO) {
+        suz = half_sum(suz);
+        rnd += lin ? c5 * suz : suz;
+      }
+      if (a.xs_out) store_rows<DT>(a.xs_out + static_cast<size_t>(k + 1) * a.B * a.d, trash, row, d_dyn, live, h, x);
+    }
+
+    // the terminal cost (losses/oc.py:290, :973) is added by k_terminal from x_out: it runs once per
+    // trajectory, and keeping every distribution's log-density out of this kernel keeps its registers free
+    store_rows<DT>(a.x_out, trash, row, a.d, live, h, x);
+    if (live && h == 0) a.rnd_out[row] = rnd;
+  }
+}
+
+// Generative control alone, u(t, x) for a whole batch at one time (unit parity tests of the drift net and
+// the ctrl wrappers against the oracle; same device code as the step loop, k = 0 of one-row tables).
+template <int DT, int SC>
+__global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const SimArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    const int n4 = sd_lds_floats(DT) / 4;
+    for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int p = lane & 31, h = lane >> 5;
+  float* trash = a.trash + tid * 4;
+  for (int tile = blockIdx.x * SD_WAVES + wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {
+    const uint32_t row = static_cast<uint32_t>(tile) * 32u + p;
+    const bool live = row < static_cast<uint32_t>(a.B);
+    f32x16 x[DT];
+    load_rows<DT>(a.x_in, row, a.d, live, h, x);
+    const float score_gain = a.coef[7], lerp_w = a.coef[8];
+    f32x16 hid[2];
+    mlp_hidden<DT>(x, hid, lds, a.temb, lane);
+    f32x16 ts[SC != SC_NONE ? DT : 1];
+    if constexpr (SC == SC_GMM) gmm_score<DT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, h, ts);
+    if constexpr (SC == SC_PHI4) phi4_score<DT>(x, a.target, a.d, h, ts);
+    float st = 1.0f;
+    if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[0] : 1.0f;
+    f32x16 u[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      u[t] = mlp_out_tile<DT>(hid, lds, t, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float uv = u[t][r];
+        if (a.clip_model > 0.0f) uv = clampf(uv, a.clip_model);
+        if constexpr (SC != SC_NONE)
+          uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * h, a.d));
+        u[t][r] = uv;
+      }
+    }
+    store_rows<DT>(a.x_out, trash, row, a.d, live, h, u);
+  }
+}
+
+template <int DT, int SC>
+static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
+  const size_t lds_bytes = static_cast<size_t>(sd_lds_floats(DT)) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_forward<DT, SC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL((k_ctrl_forward<DT, SC>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  return static_cast<int>(hipGetLastError());
+}
+#define SD_DEFINE_CTRL(DT, SC) \
+  int sd_launch_ctrl_##DT##_##SC(const SimArgs& a, int grid, hipStream_t s) { return launch_ctrl_forward<DT, SC>(a, grid, s); }
+#define SD_DECLARE_CTRL(DT, SC) int sd_launch_ctrl_##DT##_##SC(const SimArgs& a, int grid, hipStream_t s);
+
+// host-side launcher, one per instantiation (defined in sim_inst_*.hip)
+typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
+
+template <int DT, int REF, int SC, int FORM>
+static int launch_simulate(const SimArgs& a, int grid, hipStream_t stream) {
+  const size_t lds_bytes = static_cast<size_t>(sd_lds_floats(DT)) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<DT, REF, SC, FORM>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL((k_simulate<DT, REF, SC, FORM>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  return static_cast<int>(hipGetLastError());
+}
+
+#define SD_DEFINE_SIM(DT, REF, SC, FORM) \
+  int sd_launch_sim_##DT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s) { return launch_simulate<DT, REF, SC, FORM>(a, grid, s); }
+#define SD_DECLARE_SIM(DT, REF, SC, FORM) int sd_launch_sim_##DT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s);

@@ -1,0 +1,386 @@
+"""Descriptor compiler + launcher: turns the Python objects the reference's loss classes are handed
+(drift-net module, SDE, reference, target / prior distributions, time grid) into one flat
+``sdeng_desc`` (include/sdeng.h) and calls ``sdeng_simulate`` on the current HIP stream.
+
+Objects are recognised by duck typing on class name + attributes, so both the reference's own classes
+(``sde_sampler.eq.sdes.VP`` ...) and this package's mirrors are accepted.  Anything not recognised raises
+``UnsupportedByEngine`` -- there is no PyTorch re-implementation of the step loop to fall back on.
+
+Per-step scalars are computed on the host with the same 0-d fp32 torch expressions the
+reference evaluates inside its loop, so the coefficients the kernel consumes are bit-identical to the
+reference's; the table is cached per (loss, time grid).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+class UnsupportedByEngine(NotImplementedError):
+    pass
+
+
+def _name(obj):
+    return type(obj).__name__
+
+
+def _dev_f32(t: torch.Tensor, device, keep: list):
+    t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+    keep.append(t)
+    return t.data_ptr()
+
+
+def _self_of(fn):
+    return getattr(fn, "__self__", None)
+
+
+# ------------------------------------------------------------------------------------------------
+# distributions
+# ------------------------------------------------------------------------------------------------
+def dist_desc(obj, device, keep, clip=None) -> L.Dist:
+    """Distribution object -> sdeng_dist (distr/*.py parameters)."""
+    ds = L.Dist()
+    ds.clip = float(clip) if clip else 0.0
+    if obj is None:
+        ds.kind = L.DIST_NONE
+        return ds
+    n = _name(obj)
+    if n == "IsotropicGauss":
+        loc, scale = obj.loc[0, 0].detach().float().cpu(), obj.scale[0, 0].detach().float().cpu()
+        var = scale ** 2
+        ds.kind = L.DIST_ISO_GAUSS
+        ds.p0, ds.p1 = float(loc), float(scale)
+        ds.p2 = float(-0.5 * obj.dim * (2.0 * math.pi * var).log())  # distr/gauss.py:759
+        ds.p3 = float(var)
+        return ds
+    if n in ("GMM", "TwoModes", "ManyModes", "BracketTwoModes", "Gauss", "Delta"):
+        if getattr(obj, "mixture_weights", None) is None:
+            ds.kind = L.DIST_GAUSS_DIAG
+            ds.k = 1
+            ds.loc = _dev_f32(obj.loc.reshape(-1), device, keep)
+            ds.scale = _dev_f32(obj.scale.reshape(-1), device, keep)
+        else:
+            ds.kind = L.DIST_GMM_DIAG
+            ds.k = int(obj.loc.shape[0])
+            ds.loc = _dev_f32(obj.loc, device, keep)
+            ds.scale = _dev_f32(obj.scale, device, keep)
+            ds.w = _dev_f32(obj.mixture_weights, device, keep)
+        return ds
+    if n == "PhiFour":
+        if getattr(obj, "dim_phys", 1) != 1 or tuple(getattr(obj, "bc", ("dirichlet", 0))) != ("dirichlet", 0) or getattr(obj, "tilt", None):
+            raise UnsupportedByEngine("PhiFour: only the 1-D Dirichlet-0 untilted lattice")
+        ds.kind = L.DIST_PHI4
+        ds.p0, ds.p1, ds.p2 = float(obj.a), float(obj.b), float(obj.beta)
+        return ds
+    if n == "GaussFull":
+        cov = obj.cov.detach().float().cpu()
+        tril = torch.linalg.cholesky(cov)
+        ds.kind = L.DIST_GAUSS_FULL
+        ds.loc = _dev_f32(obj.loc, device, keep)
+        ds.scale = _dev_f32(obj.prec, device, keep)
+        ds.w = _dev_f32(torch.linalg.inv(tril), device, keep)
+        ds.p0 = float(tril.diagonal().log().sum())
+        return ds
+    if n in ("LogisticRegression", "SyntheticLogReg"):
+        ds.kind = L.DIST_LOGREG
+        ds.k = int(obj.X_train.shape[0])
+        ds.loc = _dev_f32(obj.X_train, device, keep)
+        ds.scale = _dev_f32(obj.y_train, device, keep)
+        ds.p0, ds.p1, ds.p2 = float(obj.weight_scale), float(obj.intercept_mean), float(obj.intercept_scale)
+        ds.p3 = float(obj.threshold)
+        return ds
+    raise UnsupportedByEngine(f"no HIP log-density/score for distribution {n}")
+
+
+def resolve_logp(fn):
+    """A log-density callable handed to the loss -> (distribution object, clip) or None if opaque."""
+    owner = _self_of(fn)
+    if owner is None:
+        return None
+    fname = getattr(fn, "__name__", "")
+    if fname == "clipped_target_unnorm_log_prob" and hasattr(owner, "target"):  # solver/oc.py:80-87
+        return owner.target, getattr(owner, "clip_target", None)
+    if fname in ("log_prob", "unnorm_log_prob") and hasattr(owner, "dim"):
+        if fname == "log_prob" and getattr(owner, "log_norm_const", 0.0) not in (0.0, None):
+            return None
+        return owner, None
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
+# drift net
+# ------------------------------------------------------------------------------------------------
+def _time_embed(te, device, keep) -> L.TimeEmbed:
+    out = L.TimeEmbed()
+    if _name(te) != "TimeEmbed" or te.channels != 64:
+        raise UnsupportedByEngine("time embedding must be TimeEmbed(channels=64)")
+    if _name(te.activation) != "GELU" or getattr(te.activation, "approximate", "none") != "none":
+        raise UnsupportedByEngine("activation must be exact-erf GELU")
+    out.coeff = _dev_f32(te.timestep_coeff.reshape(-1), device, keep)
+    out.phase = _dev_f32(te.timestep_phase.reshape(-1), device, keep)
+    n_hidden = len(te.hidden_layer)
+    if n_hidden > 4:
+        raise UnsupportedByEngine("TimeEmbed with more than 5 layers")
+    for i, layer in enumerate(te.hidden_layer):
+        out.w[i] = _dev_f32(layer.weight, device, keep)
+        out.b[i] = _dev_f32(layer.bias, device, keep)
+    out.n_hidden = n_hidden
+    out.dim_out = int(te.out_layer.weight.shape[0])
+    out.w_out = _dev_f32(te.out_layer.weight, device, keep)
+    out.b_out = _dev_f32(te.out_layer.bias, device, keep)
+    return out
+
+
+def net_desc(ctrl, device, keep) -> L.Net:
+    """ClippedCtrl / ScoreCtrl / LerpCtrl around FourierMLP(4 layers, 64 channels, GELU) -> sdeng_net."""
+    if _name(ctrl) == "AveragedModel":  # EMA wrapper (solver/oc.py:69-78)
+        ctrl = ctrl.module
+    kinds = {"ClippedCtrl": L.CTRL_CLIPPED, "ScoreCtrl": L.CTRL_SCORE, "LerpCtrl": L.CTRL_LERP}
+    if _name(ctrl) not in kinds:
+        raise UnsupportedByEngine(f"control wrapper {_name(ctrl)} has no HIP kernel")
+    net = ctrl.base_model
+    if _name(net) != "FourierMLP" or net.channels != 64 or len(net.hidden_layer) != 2 or _name(net.input_embed) != "Linear":
+        raise UnsupportedByEngine("drift net must be FourierMLP(num_layers=4, channels=64, use_angle_encoding=False)")
+    if _name(net.activation) != "GELU" or getattr(net.activation, "approximate", "none") != "none":
+        raise UnsupportedByEngine("activation must be exact-erf GELU")
+    if getattr(ctrl, "hard_constrain", False):
+        raise UnsupportedByEngine("LerpCtrl(hard_constrain=True)")
+    n = L.Net()
+    n.ctrl_kind = kinds[_name(ctrl)]
+    n.w_in, n.b_in = _dev_f32(net.input_embed.weight, device, keep), _dev_f32(net.input_embed.bias, device, keep)
+    n.w_h1, n.b_h1 = _dev_f32(net.hidden_layer[0].weight, device, keep), _dev_f32(net.hidden_layer[0].bias, device, keep)
+    n.w_h2, n.b_h2 = _dev_f32(net.hidden_layer[1].weight, device, keep), _dev_f32(net.hidden_layer[1].bias, device, keep)
+    n.w_out, n.b_out = _dev_f32(net.out_layer.weight, device, keep), _dev_f32(net.out_layer.bias, device, keep)
+    n.t_embed = _time_embed(net.timestep_embed, device, keep)
+    n.clip_model = float(ctrl.clip_model) if ctrl.clip_model else 0.0
+    if n.ctrl_kind != L.CTRL_CLIPPED:
+        n.clip_score = float(ctrl.clip_score) if ctrl.clip_score else 0.0
+        n.scale_score = float(ctrl.scale_score)
+        if ctrl.score_model is not None:
+            n.score_model = _time_embed(ctrl.score_model, device, keep)
+    return n
+
+
+def ctrl_target(ctrl):
+    """Distribution whose score ScoreCtrl/LerpCtrl mixes in (``target_score`` is a bound ``Distribution.score``)."""
+    if _name(ctrl) == "AveragedModel":
+        ctrl = ctrl.module
+    if _name(ctrl) == "ClippedCtrl":
+        return None, None
+    tgt = _self_of(ctrl.target_score)
+    if tgt is None:
+        raise UnsupportedByEngine("ScoreCtrl.target_score must be a bound Distribution.score")
+    prior = None
+    if _name(ctrl) == "LerpCtrl":
+        prior = _self_of(ctrl.prior_score)
+        if prior is None or _name(prior) != "IsotropicGauss":
+            raise UnsupportedByEngine("LerpCtrl.prior_score must be IsotropicGauss.score")
+    return tgt, prior
+
+
+# ------------------------------------------------------------------------------------------------
+# reference drift
+# ------------------------------------------------------------------------------------------------
+def resolve_reference(reference_ctrl):
+    """``reference_ctrl`` callable -> ('none'|'gaussian'|'gmm', params).  Recognises the bound
+    ``RDS.reference_ctrl`` (solver/oc.py:590-592 + ``reference_distr_utils``) and this package's
+    ``MarginalReference`` objects."""
+    if reference_ctrl is None:
+        return "none", {}
+    owner = _self_of(reference_ctrl) or reference_ctrl
+    utils = getattr(owner, "reference_distr_utils", None)
+    if utils is None:
+        raise UnsupportedByEngine("reference_ctrl is an opaque callable: pass RDS.reference_ctrl or a MarginalReference")
+    if "means_init" in utils:
+        var = utils["variances_init"]
+        if isinstance(var, tuple) or var.dim() != 2:
+            raise UnsupportedByEngine("full-covariance mixture references have no HIP kernel yet")
+        return "gmm", utils
+    if "x_init" in utils:
+        var = utils["var_init"]
+        if isinstance(var, tuple) or var.dim() != 1:
+            raise UnsupportedByEngine("full-covariance Gaussian references have no HIP kernel yet")
+        return "gaussian", utils
+    raise UnsupportedByEngine("EBM ('nn') references need autograd inside the step: not on the HIP path")
+
+
+def ref_desc(kind, utils, device, keep) -> L.Ref:
+    r = L.Ref()
+    if kind == "none":
+        r.kind = L.REF_NONE
+    elif kind == "gaussian":
+        r.kind, r.k = L.REF_GAUSS_DIAG, 1
+        r.means_init = _dev_f32(utils["x_init"].reshape(-1), device, keep)
+        r.vars_init = _dev_f32(utils["var_init"].reshape(-1), device, keep)
+    else:
+        r.kind, r.k = L.REF_GMM_DIAG, int(utils["means_init"].shape[0])
+        r.means_init = _dev_f32(utils["means_init"], device, keep)
+        r.vars_init = _dev_f32(utils["variances_init"], device, keep)
+        r.weights = _dev_f32(utils["weights_init"], device, keep)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------
+# per-step scalar tables
+# ------------------------------------------------------------------------------------------------
+def _cpu_sde(sde):
+    if sde is None:
+        return None
+    try:
+        return copy.deepcopy(sde).to("cpu")
+    except Exception:  # modules holding bound methods of other modules (ControlledLangevinSDE)
+        return sde
+
+
+def _transition_gains(sde, s, t, ddpm):
+    """(x gain, ctrl gain, noise gain) of the EI / DDPM-like kernels, with the reference's expressions
+    (eq/sdes.py:532-555 VP, :658-678 PinnedBM)."""
+    n = _name(sde)
+    if n in ("VP", "CosineVP"):
+        sig, lam = sde.scale_diff_coeff, sde.lambda_(s, t)
+        if not ddpm:
+            return torch.sqrt(1.0 + lam), 2.0 * sig ** 2 * (torch.sqrt(1.0 + lam) - 1.0), sig * torch.sqrt(lam)
+        T = sde.terminal_t
+        lam_b = 1.0 - torch.exp(sde.alpha_(T - t) - sde.alpha_(T - s))
+        la = 1.0 - torch.exp(-sde.alpha_(T - s))
+        lb = 1.0 - torch.exp(-sde.alpha_(T - t))
+        half = (sde.alpha_(sde.terminal_t - s) - sde.alpha_(sde.terminal_t - t)) / 2.0
+        var = sig ** 2 * lam_b * (lb / la)
+        return torch.sqrt(1.0 + lam), 2.0 * sig ** 2 * torch.sinh(half), torch.sqrt(var)
+    if n == "PinnedBM":
+        g, T = sde.diff_coeff, sde.terminal_t
+        var = g ** 2 * ((T - t) / (T - s)) * (t - s) if ddpm else g ** 2 * (t / s) * (t - s)
+        return t / s, g ** 2 * (t - s), torch.sqrt(var)
+    raise UnsupportedByEngine(f"{n} has no closed-form EI/DDPM transition kernel")
+
+
+def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, alpha=None, sigma=None, train=False, dim=1) -> torch.Tensor:
+    """[N,16] fp32 table (column meaning: include/sdeng.h).  ``kind``: 'ei' | 'ddpm' | 'dis_ei' | 'em' |
+    'time_reversal' | 'dds'.  ``ts`` is a CPU tensor; every entry is produced by the reference's scalar formula."""
+    ts = ts.detach().to("cpu", torch.float32)
+    N = ts.numel() - 1
+    out = torch.zeros(N, L.NCOEF, dtype=torch.float32)
+    T = ts[-1]
+    for k in range(N):
+        s, t = ts[k], ts[k + 1]
+        row = out[k]
+        row[7] = 1.0
+        if kind in ("ei", "ddpm", "dis_ei"):
+            tau = T - s
+            omega = sde.omega_ddpm(s, t) if kind == "ddpm" else sde.omega(s, t)
+            g1, g2, g3 = _transition_gains(sde, s, t, kind == "ddpm")
+            row[0], row[1], row[2], row[3] = tau, g1, g2, g3
+            row[4], row[5] = 0.5 * omega, torch.sqrt(omega)
+        elif kind == "em":
+            tau = T - s
+            dt = t - s
+            g = sde.diff(tau, None)
+            row[0], row[1], row[2], row[3] = tau, -sde.drift_coeff_t(tau), g, torch.square(g)
+            row[4], row[5] = dt, dt.sqrt()
+        elif kind == "time_reversal":
+            tau = s
+            dt = t - s
+            g = sde.diff(s, None)
+            row[0], row[1], row[2], row[3] = s, sde.drift_coeff_t(s), g, torch.square(g)
+            row[4], row[5] = dt, dt.sqrt()
+            if not train:
+                row[6] = -(sde.int_drift_coeff_t(s, t) * dim)  # losses/oc.py:1218-1219, eq/sdes.py:137-141
+        elif kind == "dds":
+            tau = s
+            dt = t - s
+            beta_k = torch.clip(alpha * dt.sqrt(), 0, 1)
+            alpha_k = torch.sqrt(1.0 - beta_k ** 2)
+            row[0], row[1] = s, alpha_k
+            row[2] = (beta_k ** 2) * (sigma ** 2)
+            row[3] = sigma * beta_k
+            row[4] = 0.5 * (beta_k ** 2 * sigma ** 2)
+            row[5] = sigma * beta_k
+        else:
+            raise ValueError(kind)
+        if lerp:  # LerpCtrl: weight t/T (reparam.py:175) and gain g(t) (reparam.py:199), at the net's time
+            t_net = row[0].clone()
+            row[7] = sde.diff(t_net, None)
+            row[8] = t_net / sde.terminal_t
+        if with_ref:  # eq/sdes.py:228-229, 247
+            s_tau = sde.s(tau)
+            row[9], row[10], row[11] = s_tau, s_tau ** 2 * sde.sigma_sq(tau), s_tau ** 2
+    return out
+
+
+
+# ------------------------------------------------------------------------------------------------
+# launch
+# ------------------------------------------------------------------------------------------------
+class Workspace:
+    """Grow-only device scratch per (device) -- the C ABI never allocates."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        cur = self.buf.get(device)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[device] = cur
+        return cur
+
+
+_WS = Workspace()
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(x: torch.Tensor):
+    if not x.is_cuda:
+        raise RuntimeError("the sdeng simulate path runs on an MI355X only: move the solver to a cuda device "
+                           "(no CPU implementation is shipped)")
+
+
+def run(desc: L.Desc, x: torch.Tensor, keep: list, return_traj=False, noise=None):
+    """Fill the I/O pointers of ``desc`` and launch.  Returns (x_N [B,d], rnd [B,1], xs or None)."""
+    require_gpu(x)
+    lib = L.lib()
+    device = x.device
+    B, d, N = x.shape[0], x.shape[1], desc.N
+    xin = x.detach().to(torch.float32).contiguous()
+    keep.append(xin)
+    x_out = torch.empty_like(xin)
+    rnd = torch.empty(B, 1, dtype=torch.float32, device=device)
+    xs = torch.empty(N + 1, B, d, dtype=torch.float32, device=device) if return_traj else None
+    desc.abi_version = L.ABI_VERSION
+    desc.B, desc.d = B, d
+    desc.x_in, desc.x_out, desc.rnd_out = xin.data_ptr(), x_out.data_ptr(), rnd.data_ptr()
+    desc.xs_out = xs.data_ptr() if return_traj else None
+    if noise is not None:
+        nz = noise.detach().to(device=device, dtype=torch.float32).contiguous()
+        assert nz.shape == (N, B, d), f"noise must be [N,B,d] = {(N, B, d)}, got {tuple(nz.shape)}"
+        keep.append(nz)
+        desc.noise_in = nz.data_ptr()
+    else:
+        desc.noise_in = None
+    need = lib.sdeng_workspace_bytes(C.byref(desc))
+    ws = _WS.get(need, device)
+    desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(lib.sdeng_simulate(C.byref(desc), _stream_ptr(device)))
+    return x_out, rnd, xs
+
+
+def logz_stats(rnd: torch.Tensor, want_weights=True):
+    """sdeng_logz -> (stats[8] device tensor, weights [B,1] or None)."""
+    require_gpu(rnd)
+    lib = L.lib()
+    device = rnd.device
+    r = rnd.detach().to(torch.float32).contiguous().view(-1)
+    stats = torch.empty(8, dtype=torch.float32, device=device)
+    w = torch.empty(r.numel(), 1, dtype=torch.float32, device=device) if want_weights else None
+    ws = torch.empty(lib.sdeng_logz_workspace_bytes(), dtype=torch.uint8, device=device)
+    L.check(lib.sdeng_logz(r.data_ptr(), r.numel(), stats.data_ptr(), w.data_ptr() if want_weights else None, ws.data_ptr(),
+                           ws.numel(), _stream_ptr(device)))
+    return stats, w

@@ -1,0 +1,220 @@
+"""Noising processes: host-side parameter holders with the reference's method names
+(``sde_sampler/eq/sdes.py``: OU :117, ConstOU :354, ScaledBM :406, VP :427, CosineVP :558,
+PinnedBM :597, ControlledLangevinSDE :78).  All per-step quantities are 0-d fp32 scalars shared by
+the batch, so these classes only produce the scalar tables the HIP step loop consumes (see
+``engine.coef_table``); the [B,d] arithmetic lives in csrc/.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+from torch.nn import Module
+
+
+def _buf(mod, name, value):
+    mod.register_buffer(name, torch.tensor(value, dtype=torch.float), persistent=False)
+
+
+class TorchSDE(Module):
+    noise_type = "diagonal"
+    sde_type = "ito"
+
+    def __init__(self, terminal_t: float = 1.0):
+        super().__init__()
+        _buf(self, "terminal_t", terminal_t)
+
+
+class ControlledLangevinSDE(TorchSDE):
+    """Annealed-Langevin path of CMCD: drift = 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T))."""
+
+    def __init__(self, target_score: Callable, prior_score: Callable, diff_coeff=1.0, terminal_t=1.0, clip_score=None, **kw):
+        super().__init__(terminal_t=terminal_t)
+        self.target_score, self.prior_score, self.clip_score = target_score, prior_score, clip_score
+        _buf(self, "diff_coeff", diff_coeff)
+
+    def drift(self, t, x):
+        w = t / self.terminal_t
+        out = self.target_score(x) * w + self.prior_score(x) * (1.0 - w)
+        out = out * (0.5 * self.diff_coeff ** 2)
+        return out if self.clip_score is None else out.clip(-self.clip_score, self.clip_score)
+
+    def diff(self, t, x):
+        return self.diff_coeff
+
+
+class OU(TorchSDE):
+    """dX = drift_coeff_t(t) X dt + diff_coeff_t(t) dW."""
+
+    def drift(self, t, x):
+        return self.drift_coeff_t(t) * x
+
+    def diff(self, t, x=None):
+        return self.diff_coeff_t(t)
+
+    def drift_div_int(self, s, t, x):
+        return self.int_drift_coeff_t(s, t) * x.shape[-1]
+
+    def transition_params(self, s, t):
+        mean = torch.exp(torch.log(self.s(t)) - torch.log(self.s(s)))
+        return mean, self.s(t) ** 2 * (self.sigma_sq(t) - self.sigma_sq(s))
+
+    def marginal_params(self, t, x_init, var_init=None, is_mixture=False):
+        """Mean / variance of the noised Gaussian at time t (diagonal var_init only in this engine)."""
+        loc = self.s(t) * x_init
+        var = self.s(t) ** 2 * self.sigma_sq(t)
+        if var_init is not None:
+            if isinstance(var_init, tuple) or var_init.dim() > x_init.dim():
+                raise NotImplementedError("full-covariance references are not supported by the HIP engine")
+            var = var + self.s(t) ** 2 * var_init
+        return loc, var
+
+    def marginal_distr(self, t, x_init, var_init=None):
+        from sde_sampler_lrds_amd.distr.gauss import Gauss
+        loc, var = self.marginal_params(t, x_init, var_init=var_init)
+        return Gauss(dim=x_init.shape[-1], loc=loc, scale=var.sqrt(), domain_tol=None)
+
+    def marginal_gmm_distr(self, t, means_init, variances_init, weights_init=None):
+        from sde_sampler_lrds_amd.distr.gauss import GMM
+        means, variances = self.marginal_params(t, means_init, var_init=variances_init, is_mixture=True)
+        w = weights_init if weights_init is not None else torch.ones(means.shape[0], device=means.device) / means.shape[0]
+        return GMM(dim=means_init.shape[-1], loc=means, scale=torch.sqrt(variances), mixture_weights=w, domain_tol=None)
+
+    def log_snr(self, t):
+        a = self.s(t)
+        noise = torch.square(a) * self.sigma_sq(t)
+        return torch.log(torch.square(a) / noise)
+
+
+class ConstOU(OU):
+    def __init__(self, drift_coeff=2.0, diff_coeff=2.0, **kw):
+        if drift_coeff < 0 or diff_coeff <= 0:
+            raise ValueError("Choose non-negative drift_coeff and positive diff_coeff.")
+        super().__init__(**kw)
+        _buf(self, "drift_coeff", drift_coeff)
+        _buf(self, "diff_coeff", diff_coeff)
+
+    def drift_coeff_t(self, t):
+        return -self.drift_coeff
+
+    def diff_coeff_t(self, t):
+        return self.diff_coeff
+
+    def int_drift_coeff_t(self, s, t):
+        return -self.drift_coeff * (t - s)
+
+    def s(self, t):
+        return torch.exp(-self.drift_coeff * t)
+
+    def sigma_sq(self, t):
+        return -0.5 * self.diff_coeff ** 2 * (1.0 - torch.exp(2.0 * self.drift_coeff * t))
+
+
+class ScaledBM(ConstOU):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, drift_coeff=0.0, **kw)
+
+    def s(self, t):
+        return torch.ones_like(t)
+
+    def sigma_sq(self, t):
+        return self.diff_coeff ** 2 * t
+
+
+class VP(OU):
+    def __init__(self, diff_coeff_sq_min=0.1, diff_coeff_sq_max=20.0, scale_diff_coeff=1.0, **kw):
+        super().__init__(**kw)
+        _buf(self, "scale_diff_coeff", scale_diff_coeff)
+        _buf(self, "diff_coeff_sq_min", diff_coeff_sq_min)
+        _buf(self, "diff_coeff_sq_max", diff_coeff_sq_max)
+
+    def _diff_coeff_sq_t(self, t):
+        return torch.lerp(self.diff_coeff_sq_min, self.diff_coeff_sq_max, t / self.terminal_t)
+
+    def drift_coeff_t(self, t):
+        return -0.5 * self._diff_coeff_sq_t(t)
+
+    def diff_coeff_t(self, t):
+        return self.scale_diff_coeff * torch.sqrt(self._diff_coeff_sq_t(t))
+
+    def int_drift_coeff_t(self, s, t):
+        return -0.25 * (self._diff_coeff_sq_t(t) + self._diff_coeff_sq_t(s)) * (t - s)
+
+    def alpha_(self, t):
+        return self.diff_coeff_sq_min * t + (0.5 * t ** 2 / self.terminal_t) * (self.diff_coeff_sq_max - self.diff_coeff_sq_min)
+
+    def transition_params(self, s, t):
+        lam = 1.0 - torch.exp(self.alpha_(s) - self.alpha_(t))
+        return torch.sqrt(1.0 - lam), self.scale_diff_coeff ** 2 * lam
+
+    def s(self, t):
+        return torch.exp(-0.5 * self.alpha_(t))
+
+    def sigma_sq(self, t):
+        return -self.scale_diff_coeff ** 2 * (1.0 - (1.0 / self.s(t) ** 2))
+
+    def _dalpha(self, a, b):
+        return self.alpha_(self.terminal_t - a) - self.alpha_(self.terminal_t - b)
+
+    def omega(self, t_k, t_k_p_1):
+        return 4.0 * self.scale_diff_coeff ** 2 * torch.tanh(self._dalpha(t_k, t_k_p_1) / 4.0)
+
+    def lambda_(self, t_k, t_k_p_1):
+        return torch.exp(self._dalpha(t_k, t_k_p_1)) - 1.0
+
+    def omega_ddpm(self, t_k, t_k_p_1):
+        la = 1.0 - torch.exp(-self.alpha_(self.terminal_t - t_k))
+        lb = 1.0 - torch.exp(-self.alpha_(self.terminal_t - t_k_p_1))
+        return self.scale_diff_coeff ** 2 * (la / lb) * self.lambda_(t_k, t_k_p_1)
+
+
+class CosineVP(VP):
+    def __init__(self, c=0.008, scale_diff_coeff=1.0, **kw):
+        super().__init__(scale_diff_coeff=scale_diff_coeff, **kw)
+        _buf(self, "c", c)
+
+    def _angle(self, t):
+        return 0.5 * torch.pi * ((t / self.terminal_t) + self.c) / (1.0 + self.c)
+
+    def _diff_coeff_sq_t(self, t):
+        return torch.pi * torch.tan(self._angle(t)) / (self.terminal_t * (1.0 + self.c))
+
+    def int_drift_coeff_t(self, s, t):
+        raise NotImplementedError("int_drift_coeff_t is not yet implemented")
+
+    def alpha_(self, t):
+        return -2.0 * torch.log(torch.cos(self._angle(t)))
+
+
+class PinnedBM(OU):
+    def __init__(self, diff_coeff=2.0, **kw):
+        if diff_coeff <= 0:
+            raise ValueError("Choose positive diff_coeff.")
+        super().__init__(**kw)
+        _buf(self, "diff_coeff", diff_coeff)
+
+    def drift_coeff_t(self, t):
+        return -1.0 / (self.terminal_t - t)
+
+    def diff_coeff_t(self, t):
+        return self.diff_coeff
+
+    def int_drift_coeff_t(self, s, t):
+        return torch.log(self.terminal_t - t) - torch.log(self.terminal_t - s)
+
+    def transition_params(self, s, t):
+        mean = (self.terminal_t - t) / (self.terminal_t - s)
+        return mean, mean * (t - s) * self.diff_coeff ** 2
+
+    def s(self, t):
+        return (self.terminal_t - t) / self.terminal_t
+
+    def sigma_sq(self, t):
+        return self.diff_coeff ** 2 * self.terminal_t * t / (self.terminal_t - t)
+
+    def omega(self, t_k, t_k_p_1):
+        return self.diff_coeff ** 2 * (t_k / t_k_p_1) * (t_k_p_1 - t_k)
+
+    def omega_ddpm(self, t_k, t_k_p_1):
+        T = self.terminal_t
+        return self.diff_coeff ** 2 * ((T - t_k) / (T - t_k_p_1)) * (t_k_p_1 - t_k)

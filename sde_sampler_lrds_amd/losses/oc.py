@@ -1,0 +1,354 @@
+"""Drop-in loss classes for the reference's ``sde_sampler/losses/oc.py`` (``conf/loss/*.yaml:_target_``).
+
+Same class names, constructor arguments, ``simulate`` / ``eval`` / ``state_dict`` surface and return types as
+the reference (``BaseOCLoss`` :14-200 and its seven subclasses), but ``simulate`` is ONE call into the HIP
+engine (csrc/) instead of a Python step loop: every step's drift-net forward, scores, noise, integrator
+update and log-RND accumulation run inside a single persistent gfx950 kernel.
+
+What is on the HIP path: the eval / sampling direction (``change_sde_ctrl=False``), i.e. what
+``Trainable.evaluate`` times as ``eval/sample_time`` (solver/oc.py:148-158).  The training direction
+(``__call__``: autograd through the net) and ``compute_eubo`` are rows f-1 / f-2 of SURVEY.md section 8 and
+are not built yet: they raise instead of silently running a PyTorch loop.
+
+Extra, engine-only knobs (keyword-only, default to the reference behaviour):
+  * ``noise=[N,B,d]`` injects the normals (replays the reference's ``randn_like`` stream, parity mode);
+    without it the kernel draws counter-based Philox normals keyed by ``self.seed`` and the global
+    particle index ``self.particle0 + row`` (independent of how the batch is sharded over GPUs).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Callable
+
+import torch
+
+from .. import _lib as L
+from .. import engine as E
+from ..utils.common import Results, make_results
+
+
+class BaseOCLoss:
+    """Mirror of losses/oc.py:14-200."""
+
+    kind = None  # coefficient-table kind of the subclass
+
+    def __init__(self, generative_ctrl: Callable, generative_ctrl_ema: Callable, sde=None, method: str = "kl",
+                 traj_per_sample: int = 1, filter_samples: Callable | None = None, max_rnd: float | None = None,
+                 sde_ctrl_dropout: float | None = None, sde_ctrl_noise: float | None = None, **kwargs):
+        self.generative_ctrl = generative_ctrl
+        self.generative_ctrl_ema = generative_ctrl_ema
+        self.sde = sde
+        if method not in ["kl", "kl_ito", "lv", "lv_traj"]:
+            raise ValueError("Unknown loss method.")
+        self.method = method
+        if traj_per_sample == 1 and self.method == "lv_traj":
+            raise ValueError("Cannot compute variance over a single trajectory.")
+        self.traj_per_sample = traj_per_sample
+        self.filter_samples = filter_samples
+        self.max_rnd = max_rnd
+        self.sde_ctrl_noise = sde_ctrl_noise
+        self.sde_ctrl_dropout = sde_ctrl_dropout
+        if self.method in ["kl", "kl_ito"]:
+            for attr in ["sde_ctrl_noise", "sde_ctrl_dropout"]:
+                if getattr(self, attr) is not None:
+                    logging.warning("%s should only be used for the log-variance loss.", attr)
+        self.n_filtered = 0
+        # engine state
+        self.seed = 1
+        self.particle0 = 0
+        self._coef_cache = {}
+        self._cpu_sde = None
+
+    # ---- reference surface -----------------------------------------------------------------
+    def filter(self, rnd, samples=None):
+        mask = True
+        if samples is not None and self.filter_samples is not None:
+            mask = self.filter_samples(samples)
+        if self.max_rnd is None:
+            return mask & rnd.isfinite()
+        return mask & (rnd < self.max_rnd)
+
+    def compute_loss(self, rnd, samples=None):
+        mask = self.filter(rnd, samples=samples)
+        assert mask.shape == rnd.shape
+        if self.method == "lv_traj":
+            rnd = rnd.reshape(self.traj_per_sample, -1, 1)
+            mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)
+            self.n_filtered += self.traj_per_sample * (mask.numel() - mask.sum()).item()
+            loss = rnd[:, mask].var(dim=0).mean()
+        else:
+            self.n_filtered += (mask.numel() - mask.sum()).item()
+            loss = rnd[mask].var() if self.method == "lv" else rnd[mask].mean()
+        return loss, {"train/n_filtered_cumulative": self.n_filtered}
+
+    @staticmethod
+    def compute_results(rnd, compute_weights=False, ts=None, samples=None, xs=None) -> Results:
+        """losses/oc.py:134-173 on the device: one sdeng_logz call gives elbo, logsumexp, variance, weights."""
+        stats, w = E.logz_stats(rnd, want_weights=compute_weights)
+        host = stats.cpu()
+        metrics = {"eval/elbo": host[0].item()}
+        preds = {}
+        if compute_weights:
+            preds["log_norm_const_is"] = host[1].item()
+            metrics["eval/lv_loss"] = host[2].item()
+            metrics["eval/norm_effective_sample_size"] = host[3].item()  # eval/metrics.py:135-140
+        return make_results(samples=samples, weights=w, log_norm_const_preds=preds, ts=ts, xs=xs, metrics=metrics)
+
+    def __call__(self, ts, x, *args, **kwargs):
+        raise E.UnsupportedByEngine(
+            "training direction (autograd through the drift net) is not on the HIP path yet (SURVEY.md 8f-1); "
+            "this engine accelerates simulate()/eval()")
+
+    def load_state_dict(self, state_dict: dict):
+        self.n_filtered = state_dict["n_filtered"]
+
+    def state_dict(self) -> dict:
+        return {"n_filtered": self.n_filtered}
+
+    # ---- engine plumbing ---------------------------------------------------------------------
+    def _ctrl(self, use_ema):
+        return self.generative_ctrl_ema if use_ema else self.generative_ctrl
+
+    def _sde_cpu(self):
+        if self._cpu_sde is None:
+            self._cpu_sde = E._cpu_sde(self.sde)
+        return self._cpu_sde
+
+    def _coef(self, ts, device, **kw):
+        key = (ts.data_ptr(), ts._version, ts.numel(), str(device), tuple(sorted((k, str(v)) for k, v in kw.items())))
+        hit = self._coef_cache.get(key)
+        if hit is None:
+            table = E.coef_table(self.kind, ts, self._sde_cpu(), **kw)
+            hit = table.to(device)
+            self._coef_cache = {key: hit}
+        return hit
+
+    def _terminal(self, desc, keep, device, terminal_unnorm_log_prob, reference_log_prob):
+        """Fill target / ref_dist + flags; returns the callables that stay opaque (evaluated with torch after)."""
+        late = []
+        res = E.resolve_logp(terminal_unnorm_log_prob) if terminal_unnorm_log_prob is not None else None
+        ctrl_tgt, _ = E.ctrl_target(self.generative_ctrl)
+        if res is not None:
+            try:
+                desc.target = E.dist_desc(res[0], device, keep, clip=res[1])
+                desc.flags |= L.FLAG_TERM_TARGET
+            except E.UnsupportedByEngine:
+                res = None
+        if res is None and terminal_unnorm_log_prob is not None:
+            late.append((-1.0, terminal_unnorm_log_prob))
+            if ctrl_tgt is not None:
+                desc.target = E.dist_desc(ctrl_tgt, device, keep)
+        if reference_log_prob is not None:
+            rr = E.resolve_logp(reference_log_prob)
+            ok = False
+            if rr is not None and desc.flags & L.FLAG_TERM_TARGET:
+                try:
+                    desc.ref_dist = E.dist_desc(rr[0], device, keep)
+                    desc.flags |= L.FLAG_TERM_REF
+                    ok = True
+                except E.UnsupportedByEngine:
+                    pass
+            if not ok:
+                late.append((1.0, reference_log_prob))
+        return late
+
+    @staticmethod
+    def _apply_late(rnd, x, late):
+        # opaque user callables: evaluated once on the device tensors, like the reference does (losses/oc.py:290)
+        if late:
+            term = 0.0
+            for sign, fn in sorted(late, key=lambda p: -p[0]):
+                term = term + sign * fn(x).view((-1, 1))
+            rnd += term
+        return rnd
+
+    def _simulate(self, ts, x, *, terminal_unnorm_log_prob, reference_log_prob=None, initial_log_prob=None, form,
+                  flags, use_ema, return_traj, noise, ref=("none", {}), coef_kw=None):
+        E.require_gpu(x)
+        device = x.device
+        keep = []
+        desc = L.Desc()
+        desc.form = form
+        desc.flags = flags
+        desc.N = ts.numel() - 1
+        desc.seed = int(self.seed)
+        desc.particle0 = int(self.particle0)
+        ctrl = self._ctrl(use_ema)
+        desc.net = E.net_desc(ctrl, device, keep)
+        desc.ref = E.ref_desc(ref[0], ref[1], device, keep)
+        late = self._terminal(desc, keep, device, terminal_unnorm_log_prob, reference_log_prob)
+        _, lerp_prior = E.ctrl_target(ctrl)
+        rnd0 = None
+        if initial_log_prob is not None:
+            pr = E.resolve_logp(initial_log_prob)
+            try:
+                if pr is None:
+                    raise E.UnsupportedByEngine("opaque")
+                desc.prior = E.dist_desc(pr[0], device, keep)
+                desc.flags |= L.FLAG_INIT_LOGP
+            except E.UnsupportedByEngine:
+                rnd0 = initial_log_prob(x).view((-1, 1))
+                if lerp_prior is not None:
+                    desc.prior = E.dist_desc(lerp_prior, device, keep)
+        elif lerp_prior is not None:
+            desc.prior = E.dist_desc(lerp_prior, device, keep)
+        coef = self._coef(ts, device, **(coef_kw or {}))
+        keep.append(coef)
+        desc.coef = coef.data_ptr()
+        x_out, rnd, xs = E.run(desc, x, keep, return_traj=return_traj, noise=noise)
+        if rnd0 is not None:
+            rnd += rnd0
+        rnd = self._apply_late(rnd, x_out, late)
+        assert rnd.shape == (x.shape[0], 1)
+        return x_out, rnd, xs
+
+    def _no_train(self, change_sde_ctrl):
+        if change_sde_ctrl:
+            raise E.UnsupportedByEngine("change_sde_ctrl=True (log-variance training) is not on the HIP path yet (SURVEY.md 8f-1)")
+
+
+class EMReferenceSDELoss(BaseOCLoss):
+    """losses/oc.py:203-428 (RDS with Euler-Maruyama; PIS when ``reference_ctrl`` is None)."""
+
+    kind = "em"
+
+    def __init__(self, *args, reference_ctrl: Callable | None = None, use_rescaling: bool = True, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.reference_ctrl = reference_ctrl
+        self.use_rescaling = use_rescaling
+
+    def simulate(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, change_sde_ctrl=False, return_traj=False,
+                 use_ema=False, *, noise=None):
+        self._no_train(change_sde_ctrl)
+        if not self.use_rescaling and type(self) is EMReferenceSDELoss:
+            raise E.UnsupportedByEngine("EMReferenceSDELoss(use_rescaling=False) scales the control twice upstream "
+                                        "(losses/oc.py:265-267); not reproduced")
+        ref = E.resolve_reference(self.reference_ctrl)
+        return self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
+                              form=L.FORM_EM if self.kind == "em" else L.FORM_LIN, flags=L.FLAG_ITO, use_ema=use_ema,
+                              return_traj=return_traj, noise=noise, ref=ref, coef_kw=dict(with_ref=ref[0] != "none"))
+
+    def compute_eubo(self, *a, **k):
+        raise E.UnsupportedByEngine("compute_eubo (noising direction) is not on the HIP path yet (SURVEY.md 8f-2)")
+
+    def eval(self, ts, x, terminal_unnorm_log_prob, reference_log_prob=None, compute_weights=True, return_traj=True,
+             use_ema=True, *, noise=None) -> Results:
+        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                         reference_log_prob=reference_log_prob, change_sde_ctrl=False,
+                                         return_traj=return_traj, use_ema=use_ema, noise=noise)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs)
+
+
+class EIReferenceSDELoss(EMReferenceSDELoss):
+    """losses/oc.py:431-568 (RDS with the exponential integrator)."""
+
+    kind = "ei"
+
+    def __init__(self, *args, reference_ctrl: Callable | None = None, **kwargs):
+        kwargs.pop("use_rescaling", None)
+        super().__init__(*args, reference_ctrl=reference_ctrl, use_rescaling=False, **kwargs)
+
+
+class DDPMLikeReferenceSDELoss(EMReferenceSDELoss):
+    """losses/oc.py:571-651 (RDS with DDPM-like transition kernels)."""
+
+    kind = "ddpm"
+
+    def __init__(self, *args, reference_ctrl: Callable | None = None, **kwargs):
+        kwargs.pop("use_rescaling", None)
+        super().__init__(*args, reference_ctrl=reference_ctrl, use_rescaling=False, **kwargs)
+
+
+class _InitialLogProbLoss(BaseOCLoss):
+    """Shared eval() of the losses that start from ``initial_log_prob`` (DIS / CMCD families)."""
+
+    def compute_eubo(self, *a, **k):
+        raise E.UnsupportedByEngine("compute_eubo (noising direction) is not on the HIP path yet (SURVEY.md 8f-2)")
+
+    def eval(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, compute_weights=True, return_traj=True,
+             use_ema=True, *, noise=None) -> Results:
+        kw = dict(compute_ito_int=compute_weights) if isinstance(self, TimeReversalLoss) else {}
+        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                         initial_log_prob=initial_log_prob, train=False, return_traj=return_traj,
+                                         use_ema=use_ema, noise=noise, **kw)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs)
+
+
+class ControlledLangevinSDELoss(_InitialLogProbLoss):
+    """losses/oc.py:654-894 (CMCD)."""
+
+    kind = "cmcd"
+
+    def __init__(self, *args, use_rescaling: bool = True, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.use_rescaling = use_rescaling
+
+    def simulate(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, train=True, change_sde_ctrl=False,
+                 return_traj=False, use_ema=False, *, noise=None):
+        raise E.UnsupportedByEngine("the CMCD step kernel (two net + two annealed-score evaluations per step) is not built yet")
+
+
+class DiscreteTimeReversalLossEI(_InitialLogProbLoss):
+    """losses/oc.py:897-1102 (DIS with the exponential integrator)."""
+
+    kind = "dis_ei"
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.use_rescaling = False
+
+    def simulate(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, train=True, change_sde_ctrl=False,
+                 return_traj=False, use_ema=False, *, noise=None):
+        self._no_train(change_sde_ctrl)
+        init = None if (train and self.method in ["kl", "kl_ito"]) else initial_log_prob
+        return self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=init,
+                              form=L.FORM_LIN, flags=L.FLAG_ITO, use_ema=use_ema, return_traj=return_traj, noise=noise)
+
+
+class TimeReversalLoss(_InitialLogProbLoss):
+    """losses/oc.py:1105-1307 (original DIS, without inference control)."""
+
+    kind = "time_reversal"
+
+    def __init__(self, *args, inference_ctrl: Callable | None = None, div_estimator: str | None = None,
+                 use_rescaling: bool = True, **kwargs):
+        super().__init__(*args, **kwargs)
+        if not use_rescaling:
+            raise ValueError("use_rescaling must be True for TimeReversalLoss.")
+        self.inference_ctrl, self.div_estimator, self.use_rescaling = inference_ctrl, div_estimator, use_rescaling
+
+    def simulate(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, train=True, compute_ito_int=False,
+                 change_sde_ctrl=False, return_traj=False, use_ema=False, *, noise=None):
+        self._no_train(change_sde_ctrl)
+        if self.inference_ctrl is not None:
+            raise E.UnsupportedByEngine("a learned inference control needs the divergence of a net (autograd): not on the HIP path")
+        init = None if (train and self.method in ["kl", "kl_ito"]) else initial_log_prob
+        lerp = type(self.generative_ctrl).__name__ == "LerpCtrl"
+        # quirk kept: TimeReversalLoss.simulate never uses the EMA net (losses/oc.py:1177-1180)
+        return self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=init,
+                              form=L.FORM_EM, flags=L.FLAG_ITO if compute_ito_int else 0, use_ema=False,
+                              return_traj=return_traj, noise=noise, coef_kw=dict(train=train, dim=x.shape[-1], lerp=lerp))
+
+
+class ExponentialIntegratorSDELoss(BaseOCLoss):
+    """losses/oc.py:1310-1467 (DDS)."""
+
+    kind = "dds"
+
+    def __init__(self, *args, alpha: float, sigma: float, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.alpha, self.sigma = alpha, sigma
+
+    def simulate(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, compute_ito_int=False, change_sde_ctrl=False,
+                 return_traj=False, use_ema=False, *, noise=None):
+        self._no_train(change_sde_ctrl)
+        return self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
+                              form=L.FORM_LIN, flags=L.FLAG_ITO if compute_ito_int else 0, use_ema=use_ema,
+                              return_traj=return_traj, noise=noise, coef_kw=dict(alpha=self.alpha, sigma=self.sigma))
+
+    def eval(self, ts, x, terminal_unnorm_log_prob, reference_log_prob=None, compute_weights=True, return_traj=True,
+             use_ema=True, *, noise=None) -> Results:
+        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                         reference_log_prob=reference_log_prob, compute_ito_int=compute_weights,
+                                         change_sde_ctrl=False, return_traj=return_traj, use_ema=use_ema, noise=noise)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs)

@@ -1,0 +1,113 @@
+"""Build the golden cases on top of the PRODUCT classes (sde_sampler_lrds_amd.*) -- the GPU parity tests
+drive the engine exactly the way a user of the reference's API would."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from sde_sampler_lrds_amd.distr.delta import Delta
+from sde_sampler_lrds_amd.distr.gauss import GMM, Gauss, GaussFull, IsotropicGauss
+from sde_sampler_lrds_amd.distr.logistic_regression import LogisticRegression
+from sde_sampler_lrds_amd.distr.phi_four import PhiFour
+from sde_sampler_lrds_amd.eq.sdes import VP, ControlledLangevinSDE, PinnedBM, ScaledBM
+from sde_sampler_lrds_amd.losses import oc
+from sde_sampler_lrds_amd.models.mlp import FourierMLP, TimeEmbed
+from sde_sampler_lrds_amd.models.reparam import ClippedCtrl, LerpCtrl, ScoreCtrl
+from sde_sampler_lrds_amd.reference import MarginalReference
+
+
+def _mlp(d):
+    return FourierMLP(dim=d, activation=torch.nn.GELU(), num_layers=4, channels=64)
+
+
+def _score_model():
+    return TimeEmbed(dim_out=1, activation=torch.nn.GELU(), num_layers=4, channels=64)
+
+
+def make_sde(m):
+    if m.get("sde", "vp") == "pbm":
+        return PinnedBM(diff_coeff=m["diff_coeff"], terminal_t=m["T"])
+    return VP(m["beta_min"], m["beta_max"], m["sigma"], terminal_t=m["T"])
+
+
+def build(c, device):
+    """-> dict(loss, ts, x0, simulate_kwargs) with every module on ``device``."""
+    m, kind, d = c.meta, c.meta["kind"], c.meta["d"]
+    out = {}
+    if kind in ("rds_gmm", "rds_default"):
+        sde = make_sde(m)
+        target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
+        ctrl = ClippedCtrl(base_model=_mlp(d), clip_model=m["clip_model"])
+        ctrl.load_state_dict(c.params("ctrl."))
+        if kind == "rds_gmm":
+            ref = MarginalReference(sde, "gmm", means_init=c["ref_means"], variances_init=c["ref_vars"], weights_init=c["ref_w"].clone())
+        else:
+            ref = MarginalReference(sde, "gaussian", x_init=c["ref_x_init"], var_init=c["ref_var_init"])
+        cls = {"ei": oc.EIReferenceSDELoss, "ddpm_like": oc.DDPMLikeReferenceSDELoss, "em": oc.EMReferenceSDELoss}[m["integrator"]]
+        mods = [sde, target, ctrl, ref]
+        for mod in mods:
+            mod.to(device)
+        loss = cls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref)
+        out.update(loss=loss, args=(target.unnorm_log_prob, ref.reference_distr.to(device).log_prob), kwargs={})
+    elif kind == "pis_phi4":
+        sde = ScaledBM(diff_coeff=m["diff_coeff"], terminal_t=m["T"])
+        target = PhiFour(a=m["a"], b=m["b"], dim=d, beta=m["beta"])
+        ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                         clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"])
+        ctrl.load_state_dict(c.params("ctrl."))
+        refd = Gauss(dim=d, loc=c["ref_loc"], scale=c["ref_scale"])
+        for mod in (sde, target, ctrl, refd):
+            mod.to(device)
+        loss = oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+        out.update(loss=loss, args=(target.unnorm_log_prob, refd.log_prob), kwargs={})
+    elif kind == "dds":
+        target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
+        prior = IsotropicGauss(dim=d, scale=m["sigma"])
+        ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                         clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"])
+        ctrl.load_state_dict(c.params("ctrl."))
+        for mod in (target, prior, ctrl):
+            mod.to(device)
+        loss = oc.ExponentialIntegratorSDELoss(ctrl, ctrl, sde=None, method="kl", alpha=m["alpha"], sigma=m["sigma"])
+        out.update(loss=loss, args=(target.unnorm_log_prob, prior.log_prob), kwargs=dict(compute_ito_int=True))
+    elif kind in ("dis_ei", "dis_orig"):
+        sde = make_sde(m)
+        target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
+        prior = IsotropicGauss(dim=d, scale=1.0)
+        if kind == "dis_ei":
+            ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                             clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"])
+        else:
+            ctrl = LerpCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                            clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"], sde=sde,
+                            prior_score=prior.score)
+        ctrl.load_state_dict(c.params("ctrl."))
+        for mod in (sde, target, prior, ctrl):
+            mod.to(device)
+        if kind == "dis_ei":
+            loss = oc.DiscreteTimeReversalLossEI(ctrl, ctrl, sde=sde, method="kl")
+            kwargs = dict(initial_log_prob=prior.log_prob, train=False)
+        else:
+            loss = oc.TimeReversalLoss(ctrl, ctrl, sde=sde, method="kl", inference_ctrl=None)
+            kwargs = dict(initial_log_prob=prior.log_prob, train=False, compute_ito_int=True)
+        out.update(loss=loss, args=(target.unnorm_log_prob,), kwargs=kwargs)
+    elif kind == "cmcd_logreg":
+        target = LogisticRegression(c["X"], c["y"], intercept_mean=m["intercept_mean"], intercept_scale=m["intercept_scale"],
+                                    weight_scale=m["weight_scale"])
+        prior = GaussFull(dim=d, loc=c["prior_loc"], cov=c["prior_cov"])
+        sde = ControlledLangevinSDE(target_score=target.score, prior_score=prior.score, diff_coeff=m["diff_coeff"],
+                                    terminal_t=m["T"], clip_score=m["clip_langevin"])
+        ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                         clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"])
+        ctrl.load_state_dict(c.params("ctrl."))
+        for mod in (target, prior, sde, ctrl):
+            mod.to(device)
+        loss = oc.ControlledLangevinSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+        out.update(loss=loss, args=(target.unnorm_log_prob,), kwargs=dict(initial_log_prob=prior.log_prob, train=False))
+    else:
+        raise KeyError(kind)
+    out["ts"] = c["ts"].to(device)
+    out["x0"] = c["x0"].to(device)
+    out["loss"].seed = m["seed"]
+    return out
