@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: particle-steps/sec of one whole ``simulate`` (+ log-Z estimators).
+
+Workload (BASELINE.json configs[1]): ManyModes d=128 (K=4), RDS with a diagonal-GMM reference, VP(0.1,10),
+exponential integrator, 65 536 particles x 256 steps per GPU, FourierMLP drift net, in-kernel Philox noise.
+A "step" of this bench = one full pass: all 256 SDE steps of the batch, terminal cost, and the
+log-Z / ESS reduction (the window the reference times as eval/sample_time, solver/oc.py:148-158),
+inputs already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rds_ei_gmm|pis_phi4]
+
+For N>1 launch with torch.distributed.run (one rank per GPU, RCCL): the particle batch is sharded
+(weak scaling: 65 536 particles per rank, Philox counters keyed by the global particle index), no
+collective inside the step loop, one all_gather of rnd[B] for the final log-Z / ESS.
+
+Prints ONE JSON line (rank 0) with the contract keys plus "roofline" and "cpu_baseline".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 (dense, = vector fp32 peak)
+
+
+def build_rds_gmm(device, B, N, d=128, K=4, seed=1):
+    from sde_sampler_lrds_amd.distr.gauss import ManyModes
+    from sde_sampler_lrds_amd.eq.sdes import VP
+    from sde_sampler_lrds_amd.losses.oc import EIReferenceSDELoss
+    from sde_sampler_lrds_amd.models.mlp import FourierMLP
+    from sde_sampler_lrds_amd.models.reparam import ClippedCtrl
+    from sde_sampler_lrds_amd.reference import MarginalReference
+    from sde_sampler_lrds_amd.utils.common import get_timesteps
+    torch.manual_seed(seed)
+    sde = VP(0.1, 10.0, 1.0, terminal_t=1.0)
+    target = ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
+    net = FourierMLP(dim=d, activation=torch.nn.GELU(), num_layers=4, channels=64)
+    with torch.no_grad():  # random-init weights of the reference architecture, last layer "alive"
+        net.out_layer.weight.uniform_(-0.1, 0.1)
+        net.out_layer.bias.uniform_(-0.1, 0.1)
+    ctrl = ClippedCtrl(base_model=net, clip_model=1e4)
+    means = target.loc.clone() + 0.1 * torch.randn(K, d)
+    ref = MarginalReference(sde, "gmm", means_init=means, variances_init=0.5 * torch.ones(K, d), weights_init=torch.ones(K))
+    for m in (sde, target, ctrl, ref):
+        m.to(device)
+    loss = EIReferenceSDELoss(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref)
+    ts = get_timesteps(0.0, 1.0, steps=N).to(device)
+    gen = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(B, d, generator=gen).to(device)
+    args = (target.unnorm_log_prob, ref.reference_distr.to(device).log_prob)
+    parts = dict(sde=sde, target=target, ctrl=ctrl, means=means, K=K, d=d)
+    flops = 2 * (2 * 64 * d + 2 * 64 * 64)  # drift-net MACs*2 per particle-step: 49 152 at d=128
+    return loss, ts, x0, args, parts, flops
+
+
+def cpu_baseline(parts, N, seed, budget_s=20.0):
+    """The CPU oracle (a port of the reference's torch CPU loop, pinned to it by tests/golden) on a bounded
+    sample of the same workload, all host cores."""
+    from oracle import sde_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    sde = orc.VP(0.1, 10.0, 1.0, 1.0)
+    tgt = orc.GMMDiag(parts["target"].loc.cpu(), parts["target"].scale.cpu(), parts["target"].mixture_weights.cpu())
+    ctrl = orc.Ctrl({k: v.cpu() for k, v in parts["ctrl"].state_dict().items()}, "clipped", clip_model=1e4)
+    means, var, w = parts["means"].cpu(), 0.5 * torch.ones(parts["K"], parts["d"]), torch.ones(parts["K"])
+
+    def ref_score(t, x):
+        loc, v = sde.marginal_diag(t, means, var)
+        return orc.mog_score(x, w, loc, v)
+
+    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+    refd = orc.GMMDiag(loc0, v0.sqrt(), w)
+    ts = orc.get_timesteps(0.0, 1.0, steps=N)
+    B = 2048
+    gen = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(B, parts["d"], generator=gen)
+    with torch.no_grad():
+        t0 = time.perf_counter()  # warm-up on a short grid
+        orc.simulate_ei_ref(ts[:9], x0, ctrl, sde, tgt.logp, refd.logp, ref_score)
+        per_step = (time.perf_counter() - t0) / 8
+        # size the sample to ~budget_s of CPU work
+        B = int(min(65536, max(1024, 2048 * budget_s / max(per_step * N, 1e-6)) // 1024 * 1024))
+        x0 = torch.randn(B, parts["d"], generator=gen)
+        t0 = time.perf_counter()
+        _, rnd, _ = orc.simulate_ei_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score)
+        orc.compute_results(rnd)
+        wall = time.perf_counter() - t0
+    return dict(value=B * N / wall, unit="particle-steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{B} particles x {N} steps of the same workload, torch CPU fp32, {wall:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=65536, help="per GPU")
+    ap.add_argument("--sde-steps", type=int, default=256)
+    ap.add_argument("--modes", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from sde_sampler_lrds_amd import _lib as L
+    from sde_sampler_lrds_amd import parallel
+    B, N = a.particles, a.sde_steps
+    loss, ts, x0, args, parts, flops_ps = build_rds_gmm(device, B, N, K=a.modes, seed=1 + rank)
+    loss.seed = 1
+    loss.particle0 = rank * B  # global particle index -> sharding-independent noise
+    ev = L.HipEvents()
+    loss.timing_events = ev
+
+    def one_pass():
+        x, rnd, _ = loss.simulate(ts, x0, *args)
+        return parallel.global_results(rnd, dist)
+
+    for _ in range(a.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = one_pass()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        wt = torch.tensor([wall], device=device)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        wall = wt.item()
+    # step-loop kernel duration: last pass's events (HIP events on the launch stream)
+    k_ms = ev.elapsed_ms()
+    # a few more individually timed launches for the average
+    samples = [k_ms]
+    for _ in range(min(5, a.steps)):
+        loss.simulate(ts, x0, *args)
+        samples.append(ev.elapsed_ms())
+    k_ms = sum(samples) / len(samples)
+
+    value = world * B * N * a.steps / wall
+    out = None
+    if rank == 0:
+        achieved = flops_ps * B * N / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "particle-steps/sec (batch*n_steps/wall)", "value": value, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ManyModes d=128 K={a.modes}, RDS gmm-ref, VP(0.1,10), EI integrator, "
+                                   f"{B} particles x {N} steps per GPU, FourierMLP(4x64) drift, Philox noise",
+                       "particles_per_gpu": B, "sde_steps": N, "parallelism": f"particle-sharded x{world}"},
+            "log_norm_const_is": res["log_norm_const_is"], "ess": res["ess"],
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "k_simulate<4,GMM,NONE,LIN>", "kernel_ms": k_ms,
+                         "algorithmic_flops_per_particle_step": flops_ps},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cb = cpu_baseline(parts, N, seed=1)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu"] = value / cb["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

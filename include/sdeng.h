@@ -169,6 +169,8 @@ typedef struct sdeng_desc {
   float cmcd_clip;       /* ControlledLangevinSDE.clip_score (<=0: none) eq/sdes.py:105-110 */
   void* workspace;       /* device scratch, >= sdeng_workspace_bytes(desc)                  */
   size_t workspace_bytes;
+  void* ev_start;        /* optional hipEvent_t recorded on `stream` right before the step-loop kernel */
+  void* ev_stop;         /* optional hipEvent_t recorded right after it (roofline timing)            */
 } sdeng_desc;
 
 /* Version of this ABI compiled into the library. */

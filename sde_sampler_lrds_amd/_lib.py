@@ -49,7 +49,8 @@ class Desc(C.Structure):
                 ("particle0", C.c_int64), ("seed", C.c_uint64),
                 ("coef", _fp), ("x_in", _fp), ("x_out", _fp), ("rnd_out", _fp), ("xs_out", _fp), ("noise_in", _fp),
                 ("net", Net), ("ref", Ref), ("target", Dist), ("ref_dist", Dist), ("prior", Dist),
-                ("cmcd_g", C.c_float), ("cmcd_clip", C.c_float), ("workspace", _fp), ("workspace_bytes", C.c_size_t)]
+                ("cmcd_g", C.c_float), ("cmcd_clip", C.c_float), ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+                ("ev_start", _fp), ("ev_stop", _fp)]
 
 
 class EngineError(RuntimeError):
@@ -101,3 +102,22 @@ def lib() -> C.CDLL:
 def check(rc: int):
     if rc != 0:
         raise EngineError(rc, lib().sdeng_last_error().decode())
+
+
+class HipEvents:
+    """A pair of raw hipEvent_t for timing the step-loop kernel alone (bench.py roofline leg)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.start, self.stop = C.c_void_p(), C.c_void_p()
+        for ev in (self.start, self.stop):
+            if self.hip.hipEventCreate(C.byref(ev)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+
+    def elapsed_ms(self) -> float:
+        if self.hip.hipEventSynchronize(self.stop) != 0:
+            raise RuntimeError("hipEventSynchronize failed")
+        ms = C.c_float()
+        if self.hip.hipEventElapsedTime(C.byref(ms), self.start, self.stop) != 0:
+            raise RuntimeError("hipEventElapsedTime failed")
+        return ms.value

@@ -206,11 +206,12 @@ __device__ float dist_logp_row(const DistEvalArgs& a, const float* x) {
     for (int c = 0; c < ds.k; ++c) {
       const float* tm = ds.tab + static_cast<size_t>(c) * 2 * a.dpad;
       const float* tv = tm + a.dpad;
-      float part = 0.0f;
+      double acc = 0.0;  // once per trajectory: accumulate the 100+ term sum in fp64 (fp32 ulp of |log p| ~ 1.5e-5)
       for (int f = 0; f < d; ++f) {
         const float dl = x[f] - tm[f];
-        part = __builtin_fmaf(dl * dl, tv[f], part);
+        acc += static_cast<double>(dl * dl) * tv[f];
       }
+      const float part = static_cast<float>(acc);
       float lp = (-0.5f * part) - ds.consts[4 * c + 2];
       if (ds.kind == SDENG_DIST_GAUSS_DIAG) { m_run = lp; l_run = 1.0f; break; }
       lp += ds.consts[4 * c + 3];
@@ -221,25 +222,28 @@ __device__ float dist_logp_row(const DistEvalArgs& a, const float* x) {
     out = m_run + logf(l_run);
   } else if (ds.kind == SDENG_DIST_ISO_GAUSS) {
     // distr/gauss.py:757-762; p0 = loc, p1 = scale, p2 = -0.5*d*log(2 pi var) (host), p3 = var
-    float part = 0.0f;
+    double acc = 0.0;
     for (int f = 0; f < d; ++f) {
       const float dl = x[f] - ds.p0;
-      part = __builtin_fmaf(dl, dl, part);
+      acc += static_cast<double>(dl) * dl;
     }
+    const float part = static_cast<float>(acc);
     out = ds.p2 - (0.5f * part) / ds.p3;
   } else if (ds.kind == SDENG_DIST_PHI4) {
     // distr/phi_four.py:44-79, 92-93
     const float coef = ds.p0 * static_cast<float>(d);
-    float grad = 0.0f, V = 0.0f, prev = 0.0f;
+    double gsum = 0.0, vsum = 0.0;
+    float prev = 0.0f;
     for (int f = 0; f < d; ++f) {
       const float xv = x[f];
       const float dl = xv - prev;
-      grad += (dl * dl) * 0.5f;
+      gsum += (dl * dl) * 0.5f;
       const float om = 1.0f - xv * xv;
-      V += (om * om) * 0.25f + ds.p1 * xv;
+      vsum += (om * om) * 0.25f + ds.p1 * xv;
       prev = xv;
     }
-    grad += (prev * prev) * 0.5f;
+    gsum += (prev * prev) * 0.5f;
+    const float grad = static_cast<float>(gsum), V = static_cast<float>(vsum);
     out = (-ds.p2) * (grad * coef + V / coef);
   } else if (ds.kind == SDENG_DIST_GAUSS_FULL) {
     // distr/gauss.py:677-699 -> MultivariateNormal.log_prob: -0.5*(d log 2pi + |L^-1 (x-mu)|^2) - sum log diag L

@@ -283,7 +283,9 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   }
 
   sim_launch_fn fn = kSimTable[dt_index(DT)][rf][sc][d->form];
+  if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
   SD_HIP(fn(a, grid_for(a.ntiles), s));
+  if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
 
   // terminal cost
   const bool tr = d->flags & SDENG_FLAG_TERM_REF, tt = d->flags & SDENG_FLAG_TERM_TARGET;

@@ -343,7 +343,7 @@ def require_gpu(x: torch.Tensor):
                            "(no CPU implementation is shipped)")
 
 
-def run(desc: L.Desc, x: torch.Tensor, keep: list, return_traj=False, noise=None):
+def run(desc: L.Desc, x: torch.Tensor, keep: list, return_traj=False, noise=None, events=None):
     """Fill the I/O pointers of ``desc`` and launch.  Returns (x_N [B,d], rnd [B,1], xs or None)."""
     require_gpu(x)
     lib = L.lib()
@@ -368,6 +368,8 @@ def run(desc: L.Desc, x: torch.Tensor, keep: list, return_traj=False, noise=None
     need = lib.sdeng_workspace_bytes(C.byref(desc))
     ws = _WS.get(need, device)
     desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel()
+    if events is not None:
+        desc.ev_start, desc.ev_stop = events.start, events.stop
     L.check(lib.sdeng_simulate(C.byref(desc), _stream_ptr(device)))
     return x_out, rnd, xs
 

@@ -58,6 +58,7 @@ class BaseOCLoss:
         self.particle0 = 0
         self._coef_cache = {}
         self._cpu_sde = None
+        self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
 
     # ---- reference surface -----------------------------------------------------------------
     def filter(self, rnd, samples=None):
@@ -195,7 +196,7 @@ class BaseOCLoss:
         coef = self._coef(ts, device, **(coef_kw or {}))
         keep.append(coef)
         desc.coef = coef.data_ptr()
-        x_out, rnd, xs = E.run(desc, x, keep, return_traj=return_traj, noise=noise)
+        x_out, rnd, xs = E.run(desc, x, keep, return_traj=return_traj, noise=noise, events=self.timing_events)
         if rnd0 is not None:
             rnd += rnd0
         rnd = self._apply_late(rnd, x_out, late)

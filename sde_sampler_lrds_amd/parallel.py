@@ -1,0 +1,57 @@
+"""Multi-GPU layer: particles are i.i.d. and never interact before the final estimator, so the batch is
+sharded across ranks (one process per GPU) with NO collective inside the step loop.  The only exchange is
+for the log-Z / ESS estimators of ``BaseOCLoss.compute_results`` (losses/oc.py:150-161): every rank reduces
+its own shard on the device (``sdeng_logz``), the 8-float partial-statistics vectors are all-gathered
+(RCCL over xGMI; 32 bytes per rank, latency-bound) and combined with a max-shifted log-sum-exp and Chan's
+parallel variance.  Noise is keyed by the global particle index, so results do not depend on the sharding.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def shard_bounds(total: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous particle range [lo, hi) of ``rank`` (first ``total % world`` ranks get one extra)."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def combine_stats(stats: torch.Tensor, counts: torch.Tensor) -> dict:
+    """stats [W,8] as written by sdeng_logz (include/sdeng.h), counts [W] -> global estimators.
+    stats[:,2] = unbiased var(rnd), [:,4] = max(-rnd), [:,5] = sum exp(-rnd-max), [:,6] = sum exp(2(-rnd-max)),
+    [:,7] = sum(-rnd)."""
+    stats, counts = stats.double().cpu(), counts.double().cpu()
+    n = counts.sum()
+    gmax = stats[:, 4].max()
+    shift = torch.exp(stats[:, 4] - gmax)
+    se = (stats[:, 5] * shift).sum()
+    se2 = (stats[:, 6] * shift ** 2).sum()
+    total = stats[:, 7].sum()
+    mean = total / n
+    local_mean = stats[:, 7] / counts
+    m2 = (stats[:, 2] * (counts - 1).clamp(min=0)).sum() + (counts * (local_mean - mean) ** 2).sum()
+    return {
+        "elbo": float(mean),
+        "log_norm_const_is": float(gmax + torch.log(se) - math.log(float(n))),
+        "lv_loss": float(m2 / (n - 1)) if n > 1 else 0.0,
+        "ess": float(se * se / se2 / n),
+        "n": int(n), "max_neg_rnd": float(gmax), "sum_exp": float(se),
+    }
+
+
+def global_results(rnd: torch.Tensor, dist=None) -> dict:
+    """Estimators over ALL ranks' particles from this rank's ``rnd`` shard [B,1] (device tensor)."""
+    from . import engine
+    stats, _ = engine.logz_stats(rnd, want_weights=False)
+    count = torch.tensor([float(rnd.shape[0])], device=rnd.device)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return combine_stats(stats.view(1, 8), count)
+    world = dist.get_world_size()
+    payload = torch.cat([stats, count])
+    gathered = torch.empty(world * 9, dtype=payload.dtype, device=payload.device)
+    dist.all_gather_into_tensor(gathered, payload)
+    gathered = gathered.view(world, 9)
+    return combine_stats(gathered[:, :8], gathered[:, 8])

@@ -1,0 +1,128 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol of include/sdeng.h
+(no compute without a GPU), the descriptor compiler and coefficient tables, the API surface of the loss
+classes, and that there is no CPU execution path."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from sde_sampler_lrds_amd import _lib as L
+from sde_sampler_lrds_amd import engine as E
+from tests import build_cases as bc
+from tests import golden_cases as gc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "sdeng.h")).read()
+    declared = set(re.findall(r"\b(sdeng_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in include/sdeng.h but not exported"
+    assert set(L.EXPORTS) <= declared
+    lib.sdeng_abi_version.restype = ctypes.c_int
+    assert lib.sdeng_abi_version() == L.ABI_VERSION
+
+
+def test_struct_sizes_match_header_layout():
+    # sizes the C compiler produces for the same field lists (checked once with hipcc: see DESIGN.md)
+    assert ctypes.sizeof(L.Dist) == 56
+    assert ctypes.sizeof(L.TimeEmbed) == 104
+    assert ctypes.sizeof(L.Ref) == 32
+
+
+def test_workspace_bytes_and_bad_descriptors_without_gpu():
+    lib = L.lib()
+    d = L.Desc()
+    d.abi_version, d.B, d.d, d.N = L.ABI_VERSION, 1024, 128, 256
+    d.ref.kind, d.ref.k = L.REF_GMM_DIAG, 4
+    need = lib.sdeng_workspace_bytes(ctypes.byref(d))
+    assert need > 256 * 4 * 2 * 128 * 4  # at least the per-step reference tables
+    d.d = 129
+    assert lib.sdeng_workspace_bytes(ctypes.byref(d)) == 0
+    rc = lib.sdeng_simulate(ctypes.byref(d), None)
+    assert rc == L.E_INVALID and b"d" in lib.sdeng_last_error()
+    d.d, d.abi_version = 128, 99
+    assert lib.sdeng_simulate(ctypes.byref(d), None) == L.E_INVALID
+
+
+@pytest.mark.parametrize("name", [n for n in gc.SIM_CASES if n != "cmcd_logreg_d61"])
+def test_descriptor_compiles_on_host(name):
+    c = gc.load(name)
+    b = bc.build(c, "cpu")
+    loss = b["loss"]
+    keep = []
+    net = E.net_desc(loss.generative_ctrl, "cpu", keep)
+    assert net.w_in and net.t_embed.dim_out == 64
+    kind, utils = E.resolve_reference(getattr(loss, "reference_ctrl", None))
+    ref = E.ref_desc(kind, utils, "cpu", keep)
+    assert ref.kind in (L.REF_NONE, L.REF_GAUSS_DIAG, L.REF_GMM_DIAG)
+    tgt = E.resolve_logp(b["args"][0])
+    assert tgt is not None and E.dist_desc(tgt[0], "cpu", keep).kind != L.DIST_NONE
+
+
+def test_coef_table_matches_reference_scalars():
+    """Per-step coefficients are the reference's own scalar formulas (checked against the oracle, which is
+    pinned to the reference bit for bit in test_oracle_golden.test_sde_scalars)."""
+    from oracle import sde_oracle as orc
+    from sde_sampler_lrds_amd.eq.sdes import VP, PinnedBM
+    ts = torch.linspace(0.0, 1.0, 17)
+    tab = E.coef_table("ei", ts, VP(0.1, 10.0, 1.3, terminal_t=1.0), with_ref=True)
+    o = orc.VP(0.1, 10.0, 1.3, 1.0)
+    for k in range(16):
+        s, t = ts[k], ts[k + 1]
+        lam = o.lam(s, t)
+        assert tab[k, 0] == ts[-1] - s
+        assert tab[k, 1] == torch.sqrt(1.0 + lam)
+        assert tab[k, 2] == 2.0 * o.sig ** 2 * (torch.sqrt(1.0 + lam) - 1.0)
+        assert tab[k, 3] == o.sig * torch.sqrt(lam)
+        assert tab[k, 4] == 0.5 * o.omega(s, t) and tab[k, 5] == torch.sqrt(o.omega(s, t))
+        tau = ts[-1] - s
+        assert tab[k, 9] == o.s(tau) and tab[k, 10] == o.s(tau) ** 2 * o.sigma_sq(tau) and tab[k, 11] == o.s(tau) ** 2
+    tsp = torch.linspace(0.05, 4.9, 9)
+    tabp = E.coef_table("ddpm", tsp, PinnedBM(diff_coeff=0.4472135954999579, terminal_t=5.0))
+    op = orc.PinnedBM(0.4472135954999579, 5.0)
+    for k in range(8):
+        assert tabp[k, 4] == 0.5 * op.omega_ddpm(tsp[k], tsp[k + 1])
+        assert tabp[k, 1] == tsp[k + 1] / tsp[k]
+
+
+def test_no_cpu_execution_path():
+    c = gc.load("rds_ei_gmm_d8_k4")
+    b = bc.build(c, "cpu")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        b["loss"].simulate(b["ts"], b["x0"], *b["args"])
+    with pytest.raises(E.UnsupportedByEngine):
+        b["loss"](b["ts"], b["x0"], *b["args"])  # training direction: not built, and says so
+
+
+def test_loss_surface_matches_reference_names():
+    from sde_sampler_lrds_amd.losses import oc
+    for cls in ["BaseOCLoss", "EMReferenceSDELoss", "EIReferenceSDELoss", "DDPMLikeReferenceSDELoss",
+                "ControlledLangevinSDELoss", "DiscreteTimeReversalLossEI", "TimeReversalLoss", "ExponentialIntegratorSDELoss"]:
+        assert hasattr(oc, cls)
+    with pytest.raises(ValueError, match="Unknown loss method"):
+        oc.BaseOCLoss(None, None, method="nope")
+    with pytest.raises(ValueError, match="single trajectory"):
+        oc.BaseOCLoss(None, None, method="lv_traj", traj_per_sample=1)
+    l = oc.BaseOCLoss(None, None)
+    l.load_state_dict({"n_filtered": 3})
+    assert l.state_dict() == {"n_filtered": 3}
+
+
+def test_mirror_modules_match_oracle_on_cpu():
+    """The host-side torch forward of the mirrors (API surface, not the simulate path) equals the oracle."""
+    from oracle import sde_oracle as orc
+    c = gc.load("pis_em_phi4_d100")
+    b = bc.build(c, "cpu")
+    ctrl = b["loss"].generative_ctrl
+    tgt = orc.PhiFour(c.meta["a"], c.meta["b"], c.meta["d"], c.meta["beta"])
+    o = orc.Ctrl(c.params("ctrl."), "score", clip_model=1e4, target_score=tgt.score, clip_score=1e4, scale_score=1.0)
+    t = c["ts"][-1] - c["ts"][c.meta["N"] // 2]
+    with torch.no_grad():
+        assert gc.rel_err(ctrl(t, c["x_mid"]), c["u_mid"]) < 1e-6
+    assert gc.rel_err(o(t, c["x_mid"]), c["u_mid"]) < 1e-6
