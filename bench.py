@@ -62,11 +62,29 @@ def build_rds_gmm(device, B, N, d=128, K=4, seed=1):
     return loss, ts, x0, args, parts, flops
 
 
+def host_cores() -> int:
+    """CPU share of this process: cgroup quota if one is set, else the affinity mask, capped at 16 (the share a
+    one-GPU box grants; the machine itself reports hundreds of cores and oversubscribing them stalls torch)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(parts, N, seed, budget_s=20.0):
     """The CPU oracle (a port of the reference's torch CPU loop, pinned to it by tests/golden) on a bounded
     sample of the same workload, all host cores."""
     from oracle import sde_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = host_cores()
+    torch.set_num_threads(cores)
     sde = orc.VP(0.1, 10.0, 1.0, 1.0)
     tgt = orc.GMMDiag(parts["target"].loc.cpu(), parts["target"].scale.cpu(), parts["target"].mixture_weights.cpu())
     ctrl = orc.Ctrl({k: v.cpu() for k, v in parts["ctrl"].state_dict().items()}, "clipped", clip_model=1e4)
@@ -79,15 +97,17 @@ def cpu_baseline(parts, N, seed, budget_s=20.0):
     loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
     refd = orc.GMMDiag(loc0, v0.sqrt(), w)
     ts = orc.get_timesteps(0.0, 1.0, steps=N)
-    B = 2048
     gen = torch.Generator().manual_seed(seed)
-    x0 = torch.randn(B, parts["d"], generator=gen)
+    probe_b = 4096
+    x0 = torch.randn(probe_b, parts["d"], generator=gen)
     with torch.no_grad():
-        t0 = time.perf_counter()  # warm-up on a short grid
+        orc.simulate_ei_ref(ts[:5], x0, ctrl, sde, tgt.logp, refd.logp, ref_score)  # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
         orc.simulate_ei_ref(ts[:9], x0, ctrl, sde, tgt.logp, refd.logp, ref_score)
-        per_step = (time.perf_counter() - t0) / 8
-        # size the sample to ~budget_s of CPU work
-        B = int(min(65536, max(1024, 2048 * budget_s / max(per_step * N, 1e-6)) // 1024 * 1024))
+        rate = probe_b * 8 / (time.perf_counter() - t0)  # particle-steps/s of the probe
+        # size the sample to ~budget_s of CPU work over the FULL N-step grid
+        B = int(max(1024, min(65536, 0.3 * rate * budget_s / N) // 1024 * 1024))  # short probes run ~3x hot
+        print(f"[cpu_baseline] probe {rate:.3e} p-steps/s on {cores} threads -> sample of {B} particles", file=sys.stderr, flush=True)
         x0 = torch.randn(B, parts["d"], generator=gen)
         t0 = time.perf_counter()
         _, rnd, _ = orc.simulate_ei_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score)
