@@ -6,12 +6,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/sdeng.h"
 #include "prep_kernels.hpp"
 #include "sim_common.hpp"
 
-enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2 };
+enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
 
 typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
@@ -19,7 +20,7 @@ typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
 #define SD_DECLARE_CTRL(DT, SC) int sd_launch_ctrl_##DT##_##SC(const SimArgs& a, int grid, hipStream_t s);
 #define SD_FOR_FORM(M, DT, REF, SC) M(DT, REF, SC, 0) M(DT, REF, SC, 1)
 #define SD_FOR_SC(M, DT, REF) SD_FOR_FORM(M, DT, REF, 0) SD_FOR_FORM(M, DT, REF, 1) SD_FOR_FORM(M, DT, REF, 2)
-#define SD_FOR_REF(M, DT) SD_FOR_SC(M, DT, 0) SD_FOR_SC(M, DT, 1) SD_FOR_SC(M, DT, 2)
+#define SD_FOR_REF(M, DT) SD_FOR_SC(M, DT, 0) SD_FOR_SC(M, DT, 1) SD_FOR_SC(M, DT, 2) SD_FOR_SC(M, DT, 3)
 SD_FOR_REF(SD_DECLARE_SIM, 1)
 SD_FOR_REF(SD_DECLARE_SIM, 2)
 SD_FOR_REF(SD_DECLARE_SIM, 4)
@@ -29,10 +30,10 @@ SD_CTRL_ROW(SD_DECLARE_CTRL, 2)
 SD_CTRL_ROW(SD_DECLARE_CTRL, 4)
 
 #define SD_ENTRY(DT, REF, SC, FORM) sd_launch_sim_##DT##_##REF##_##SC##_##FORM,
-static const sim_launch_fn kSimTable[3][3][3][2] = {
+static const sim_launch_fn kSimTable[3][4][3][2] = {
 #define SD_TAB_FORM(DT, REF, SC) {SD_ENTRY(DT, REF, SC, 0) SD_ENTRY(DT, REF, SC, 1)},
 #define SD_TAB_SC(DT, REF) {SD_TAB_FORM(DT, REF, 0) SD_TAB_FORM(DT, REF, 1) SD_TAB_FORM(DT, REF, 2)},
-#define SD_TAB_REF(DT) {SD_TAB_SC(DT, 0) SD_TAB_SC(DT, 1) SD_TAB_SC(DT, 2)},
+#define SD_TAB_REF(DT) {SD_TAB_SC(DT, 0) SD_TAB_SC(DT, 1) SD_TAB_SC(DT, 2) SD_TAB_SC(DT, 3)},
     SD_TAB_REF(1) SD_TAB_REF(2) SD_TAB_REF(4)};
 #define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
 static const sim_launch_fn kCtrlTable[3][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}};
@@ -203,6 +204,18 @@ static int score_kind(const sdeng_desc* d, int& sc) {
   return 0;
 }
 
+// start delay of the second half of each workgroup's waves (units of ~8k cycles); SDENG_STAGGER overrides
+static int stagger_units() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SDENG_STAGGER");
+    v = e ? atoi(e) : 4;
+    if (v < 0) v = 0;
+    if (v > 64) v = 64;
+  }
+  return v;
+}
+
 static int grid_for(int ntiles) {
   int g = (ntiles + SD_WAVES - 1) / SD_WAVES;
   if (g > 256) g = 256;  // one persistent workgroup per CU (LDS image + 2 waves/SIMD fill a CU)
@@ -236,6 +249,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   a.xs_out = d->xs_out; a.noise_in = d->noise_in;
   a.trash = ws + L.trash;
   a.ntiles = (d->B + 31) / 32;
+  a.stagger = stagger_units();
 
   int rc = prepare_net(d, L, ws, DT, a, s, d->N, false, 0.0f);
   if (rc) return rc;
@@ -246,13 +260,13 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   // reference drift tables
   int rf = RF_NONE;
   if (d->ref.kind == SDENG_REF_GAUSS_DIAG || d->ref.kind == SDENG_REF_GMM_DIAG) {
-    rf = d->ref.kind == SDENG_REF_GAUSS_DIAG ? RF_GAUSS : RF_GMM;
-    const int K = rf == RF_GAUSS ? 1 : d->ref.k;
+    const int K = d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k;
+    rf = d->ref.kind == SDENG_REF_GAUSS_DIAG ? RF_GAUSS : (K <= 4 ? RF_GMM : RF_GMM_BIG);
     if (K < 1 || !d->ref.means_init || !d->ref.vars_init) return fail(SDENG_E_INVALID, "reference: null means/vars or k < 1");
     if (d->N > 0) {
       RefTabArgs r;
       r.K = K; r.d = d->d; r.dpad = dpad; r.coef = d->coef;
-      r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = rf == RF_GMM ? d->ref.weights : nullptr;
+      r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = rf != RF_GAUSS ? d->ref.weights : nullptr;
       r.tab = ws + L.ref_tab; r.consts = ws + L.ref_consts;
       SD_HIP(sd_launch_ref_tables(r, d->N, s));
     }

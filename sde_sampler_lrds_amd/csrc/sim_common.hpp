@@ -77,4 +77,5 @@ struct SimArgs {
   float* trash;           // [SD_THREADS*4] dump slots for masked stores
   float cmcd_g, cmcd_clip;
   int ntiles;
+  int stagger;            // start delay of waves 4..7, in units of s_sleep(127) (~8k cycles): see k_simulate
 };

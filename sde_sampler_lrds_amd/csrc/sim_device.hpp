@@ -238,6 +238,72 @@ SD_INLINE void gmm_score(const f32x16 (&x)[DT], const float* __restrict__ tab, c
     for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
 }
 
+// Small-mixture variant (K <= SD_KREG; the reference's default n_modes is 4, conf/target/many_modes.yaml): component responsibilities p_k = softmax_k(log w_k + log N_k(x)) are
+// computed once (pass 1) and kept in registers; the score of a feature is then assembled where it is
+// consumed, sum_k p_k (m_k - x) / var_k, so no d-wide score array stays live across the output layer.
+#define SD_KREG 4
+template <int DT>
+SD_INLINE void gmm_resp(const f32x16 (&x)[DT], const float* __restrict__ tab, const float* __restrict__ consts,
+                        int cstride, int K, float c1, int h, float (&p)[SD_KREG]) {
+  constexpr int dpad = 32 * DT;
+  float lp[SD_KREG];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) {
+    lp[k] = -INFINITY;
+    if (k < K) {
+      const float* mp = tab + static_cast<size_t>(k) * 2 * dpad + 4 * h;
+      const float* vp = mp + dpad;
+      float part = 0.0f;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(mp + 32 * t + 8 * q);
+          const f32x4 iv = *reinterpret_cast<const f32x4*>(vp + 32 * t + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dl = x[t][4 * q + e] - m[e];
+            part = __builtin_fmaf(dl * dl, iv[e], part);
+          }
+        }
+      part = half_sum(part);
+      float v = ((-0.5f * part) - c1) - consts[k * cstride + 0];  // distr/gauss.py:70-72
+      v = consts[k * cstride + 1] + v;                           // torch.log(weights) + log_prob
+      lp[k] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  float den = 0.0f;
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) {
+    p[k] = (k < K) ? expf(lp[k] - mx) : 0.0f;
+    den += p[k];
+  }
+  const float inv = 1.0f / den;
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) p[k] *= inv;
+}
+
+// score of the four features of quad (t, q) from the responsibilities: -sum_k p_k (x - m_k)/var_k
+template <int DT>
+SD_INLINE f32x4 gmm_score_quad(const f32x16 (&x)[DT], const float* __restrict__ tab, int K, int h, const float (&p)[SD_KREG],
+                               int t, int q) {
+  constexpr int dpad = 32 * DT;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) {
+    if (k < K) {
+      const float* mp = tab + static_cast<size_t>(k) * 2 * dpad + 4 * h + 32 * t + 8 * q;
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mp);
+      const f32x4 iv = *reinterpret_cast<const f32x4*>(mp + dpad);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(p[k], (m[e] - x[t][4 * q + e]) * iv[e], acc[e]);
+    }
+  }
+  return acc;
+}
+
 // Gaussian (one component) score: -(x - mean)/var  (distr/gauss.py:124-126)
 template <int DT>
 SD_INLINE void gauss_score(const f32x16 (&x)[DT], const float* __restrict__ tab, int h, f32x16 (&acc)[DT]) {

@@ -10,7 +10,7 @@
 #pragma once
 #include "sim_device.hpp"
 
-enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2 };
+enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };  // GMM: K <= SD_KREG (responsibilities in registers)
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
 
 // score part of the generative control for one feature tile (added to clip(net)):
@@ -27,11 +27,13 @@ SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, 
   if (a.clip_score > 0.0f) sv = clampf(sv, a.clip_score);
   float v = a.scale_score * sv;
   v = v * st;
-  v = lerp ? score_gain * v : v;
-  return in_range ? v : 0.0f;
+  if (lerp) v = in_range ? score_gain * v : 0.0f;  // only the prior term can be non-zero on a pad feature
+  return v;
 }
 
-template <int DT, int REF, int SC, int FORM>
+// PAR = 1 adds the parity-mode paths (injected noise, trajectory dump); PAR = 0 keeps them out of the step loop,
+// whose code must stay inside the 64 KB instruction cache two CUs share.
+template <int DT, int REF, int SC, int FORM, int PAR>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const SimArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int dpad = 32 * DT;
@@ -45,6 +47,13 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
   }
   __syncthreads();
+  // Stagger: the two waves that share a SIMD run the same program and would stay in lockstep (both in their
+  // MFMA phase, then both in their VALU phase, sharing each pipe in turn).  Delaying the second-dispatched half
+  // by about half a step puts one wave's matrix phase beside its partner's vector phase for the whole
+  // trajectory (MI355X_MICROARCH.md, 'Two waves per SIMD', item 9).  Results do not depend on it.
+  if (wave >= SD_WAVES / 2) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int p = lane & 31, h = lane >> 5;
   constexpr bool lin = FORM == SDENG_FORM_LIN;
   const bool full_d = a.d == dpad;
@@ -59,7 +68,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     // rnd0 = log p_prior(x0) when the loss asks for it (losses/oc.py:695-699, 935-939), from k_dist_eval
     float rnd = 0.0f;
     if (a.rnd_init) rnd = (live ? a.rnd_init[row] : 0.0f);
-    if (a.xs_out) store_rows<DT>(a.xs_out, trash, row, a.d, live, h, x);
+    if constexpr (PAR) {
+      if (a.xs_out) store_rows<DT>(a.xs_out, trash, row, a.d, live, h, x);
+    }
 
     for (int k = 0; k < a.N; ++k) {
       const float* cf = a.coef + static_cast<size_t>(k) * SDENG_NCOEF;
@@ -79,12 +90,14 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       f32x16 ts[SC != SC_NONE ? DT : 1];
       if constexpr (SC == SC_GMM) gmm_score<DT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, h, ts);
       if constexpr (SC == SC_PHI4) phi4_score<DT>(x, a.target, d_dyn, h, ts);
-      f32x16 rs[REF != RF_NONE ? DT : 1];
-      if constexpr (REF == RF_GMM) {  // eq/sdes.py:329-345
-        gmm_score<DT>(x, a.ref_tab + static_cast<size_t>(k) * a.ref_k * 2 * dpad,
-                      a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2, 2, a.ref_k, a.ref_c1, h, rs);
-      }
-      if constexpr (REF == RF_GAUSS) gauss_score<DT>(x, a.ref_tab + static_cast<size_t>(k) * 2 * dpad, h, rs);  // :265-279
+      // reference drift (eq/sdes.py:265-279, 329-345): small mixtures keep only the K responsibilities and
+      // assemble the score quad by quad in the tail; larger ones use the online-softmax accumulator
+      const float* rtab = a.ref_tab + static_cast<size_t>(k) * a.ref_k * 2 * dpad;
+      const float* rcs = a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2;
+      float resp[REF == RF_GMM ? SD_KREG : 1];
+      f32x16 rs[REF == RF_GMM_BIG ? DT : 1];
+      if constexpr (REF == RF_GMM) gmm_resp<DT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, h, resp);
+      if constexpr (REF == RF_GMM_BIG) gmm_score<DT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, h, rs);
       __builtin_amdgcn_sched_barrier(0);
       float st = 1.0f;
       if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[k] : 1.0f;
@@ -107,14 +120,31 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         for (int q = 0; q < 4; ++q) {
           const int fb = 32 * t + 8 * q + 4 * h;
           f32x4 z;
-          if (a.noise_in) {
+          if (PAR && a.noise_in) {
             z = load_quad(a.noise_in + static_cast<size_t>(k) * a.B * a.d, row, d_dyn, live, t, q, h);
           } else {
             z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(fb >> 2), 0u, a.seed_lo, a.seed_hi);
-            if (!full_d) {
+            // pad features (f >= d) may carry noise: their weights, table entries and outputs are all zero, so
+            // they never reach a live feature -- except through the phi^4 lattice's neighbour coupling
+            if constexpr (SC == SC_PHI4) {
+              if (!full_d) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) z[e] = feat_lt(t, 4 * q + e, 4 * h, d_dyn) ? z[e] : 0.0f;
+                for (int e = 0; e < 4; ++e) z[e] = feat_lt(t, 4 * q + e, 4 * h, d_dyn) ? z[e] : 0.0f;
+              }
             }
+          }
+          f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};  // reference score of this quad
+          if constexpr (REF == RF_GMM) rq = gmm_score_quad<DT>(x, rtab, a.ref_k, h, resp, t, q);
+          if constexpr (REF == RF_GMM_BIG) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rq[e] = rs[t][4 * q + e];
+          }
+          if constexpr (REF == RF_GAUSS) {
+            const float* mp = rtab + 4 * h + 32 * t + 8 * q;
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mp);
+            const f32x4 iv = *reinterpret_cast<const f32x4*>(mp + dpad);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rq[e] = -((x[t][4 * q + e] - m[e]) * iv[e]);  // distr/gauss.py:124-126
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -122,13 +152,13 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
             const float xv = x[t][r], uv = u[r];
             if constexpr (lin) {  // eq/sdes.py:535-538: ret = c1*x + c2*(ref + u); ret += c3*z
               float sc = uv;
-              if constexpr (REF != RF_NONE) sc = rs[t][r] + uv;
+              if constexpr (REF != RF_NONE) sc = rq[e] + uv;
               x[t][r] = (c1 * xv + c2 * sc) + c3 * z[e];
               suz = __builtin_fmaf(uv, z[e], suz);
             } else {  // losses/oc.py:277-284
               const float db = z[e] * c5;
               float f = c1 * xv;
-              if constexpr (REF != RF_NONE) f = f + c3 * rs[t][r];
+              if constexpr (REF != RF_NONE) f = f + c3 * rq[e];
               x[t][r] = xv + (f + c2 * uv) * c4 + c2 * db;
               suz = __builtin_fmaf(uv, db, suz);
             }
@@ -144,7 +174,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         suz = half_sum(suz);
         rnd += lin ? c5 * suz : suz;
       }
-      if (a.xs_out) store_rows<DT>(a.xs_out + static_cast<size_t>(k + 1) * a.B * a.d, trash, row, d_dyn, live, h, x);
+      if constexpr (PAR) {
+        if (a.xs_out) store_rows<DT>(a.xs_out + static_cast<size_t>(k + 1) * a.B * a.d, trash, row, d_dyn, live, h, x);
+      }
     }
 
     // the terminal cost (losses/oc.py:290, :973) is added by k_terminal from x_out: it runs once per
@@ -217,14 +249,19 @@ static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
 // host-side launcher, one per instantiation (defined in sim_inst_*.hip)
 typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
 
-template <int DT, int REF, int SC, int FORM>
-static int launch_simulate(const SimArgs& a, int grid, hipStream_t stream) {
+template <int DT, int REF, int SC, int FORM, int PAR>
+static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(sd_lds_floats(DT)) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<DT, REF, SC, FORM>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<DT, REF, SC, FORM, PAR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_simulate<DT, REF, SC, FORM>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_simulate<DT, REF, SC, FORM, PAR>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
+}
+template <int DT, int REF, int SC, int FORM>
+static int launch_simulate(const SimArgs& a, int grid, hipStream_t stream) {
+  if (a.noise_in || a.xs_out) return launch_simulate_par<DT, REF, SC, FORM, 1>(a, grid, stream);
+  return launch_simulate_par<DT, REF, SC, FORM, 0>(a, grid, stream);
 }
 
 #define SD_DEFINE_SIM(DT, REF, SC, FORM) \

@@ -1,0 +1,36 @@
+#!/bin/bash
+# rocprofv3 counter passes over the cfg-2 step-loop kernel (one --pmc set per run; no tracing flags).
+# usage: tools/pmc_passes.sh <tag>
+set -u
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+export PROBE_REPS=2
+i=0
+for SET in \
+  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
+  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" \
+  "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM SQ_WAVES" \
+  "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" \
+  "SQC_TC_INST_REQ SQC_TC_DATA_READ_REQ SQC_TC_STALL SQC_DCACHE_MISSES" \
+  "FETCH_SIZE GRBM_GUI_ACTIVE" \
+  "WRITE_SIZE GRBM_GUI_ACTIVE" ; do
+  i=$((i+1))
+  timeout -k 10 120 rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- python $GRAFT_REPO_ROOT/tools/bench_kernel_only.py > $OUT/p$i.log 2>&1
+  echo "pass $i rc=$?" >> $OUT/summary.txt
+done
+python - <<PY
+import csv, glob, collections, os
+out = "$OUT"
+acc = collections.defaultdict(list)
+for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_simulate" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(out + "/summary.txt", "a") as fo:
+    for k in sorted(acc):
+        v = acc[k]
+        line = f"{k:32s} mean/dispatch {sum(v)/len(v):.6g}  (n={len(v)})"
+        print(line); fo.write(line + "\n")
+PY
