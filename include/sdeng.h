@@ -144,7 +144,7 @@ typedef struct sdeng_ref {
 /* ---- noise ---------------------------------------------------------------------------------
  * noise_in != NULL : injected, z[k] = noise_in[k*B*d ...] -- replays the reference's one
  *                    randn_like(x) per step (losses/oc.py:277, eq/sdes.py:537, losses/oc.py:722, 1372, 1222);
- * noise_in == NULL : counter-based Philox4x32-10, counter (step, feature/4, particle0+p, stream), key = seed,
+ * noise_in == NULL : counter-based Philox4x32-10, counter (particle0+p, feature/4, step, stream), key = seed,
  *                    two Box-Muller pairs on u = ((bits>>9)+0.5)*2^-23; independent of sharding.
  */
 typedef struct sdeng_desc {

@@ -624,13 +624,13 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def philox_normal(seed: int, step: int, particle0: int, B: int, d: int, stream: int = 0) -> torch.Tensor:
     """Engine noise definition ("identical seeds" mode): the four normals of features
     4j..4j+3 of global particle p at step k come from Philox4x32-10 with counter
-    (k, j, p, stream) and key (seed_lo, seed_hi), through two Box-Muller pairs on
+    (p, j, k, stream) and key (seed_lo, seed_hi), through two Box-Muller pairs on
     u = ((bits >> 9) + 0.5) * 2^-23.  Independent of batch sharding by construction."""
     nj = (d + 3) // 4
     p = (np.arange(B, dtype=np.uint64) + np.uint64(particle0))[:, None].astype(np.uint32)
     j = np.arange(nj, dtype=np.uint32)[None, :]
     pp, jj = np.broadcast_arrays(p, j)
-    r = philox4x32_10(np.full_like(pp, step), jj, pp, np.full_like(pp, stream), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    r = philox4x32_10(pp, jj, np.full_like(pp, step), np.full_like(pp, stream), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     u = [((ri >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23) for ri in r]
     out = np.empty((B, nj, 4), dtype=np.float32)
     two_pi = np.float32(2.0 * math.pi)

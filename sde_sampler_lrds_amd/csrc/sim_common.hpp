@@ -28,9 +28,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SD_THREADS (SD_WAVES * 64)
 
 __host__ __device__ inline int sd_lds_floats(int DT) {
-  // W_in (2*DT tiles-pairs) + W_h1 + W_h2 (4 each) + W_out (DT*2), 1024 floats per (out-tile,in-tile) pair,
-  // then b_in, b_h1, b_h2 (64 each) and b_out (32*DT)
+  // packed image: W_in (2*DT tile pairs) + W_h1 + W_h2 (4 each) + W_out (DT*2), 1024 floats per (out-tile,in-tile)
+  // pair, then b_in, b_h1, b_h2 (64 each) and b_out (32*DT).  The weights live in LDS; the biases are read from
+  // the global copy (a few hundred bytes, L1-resident) so that LDS keeps room for per-wave reference tables.
   return (2 * DT + 4 + 4 + 2 * DT) * 1024 + 3 * 64 + 32 * DT;
+}
+// per-wave LDS copy of one step's reference table [K][2][dpad]; available while K*2*dpad <= SD_REFTAB_FLOATS
+#define SD_REFTAB_FLOATS 1024
+__host__ __device__ inline int sd_lds_weight_floats(int DT) { return (4 * DT + 8) * 1024; }
+__host__ __device__ inline int sd_lds_total_bytes(int DT, bool with_ref) {
+  return (sd_lds_weight_floats(DT) + (with_ref ? SD_WAVES * SD_REFTAB_FLOATS : 0)) * 4;
 }
 __host__ __device__ inline int sd_off_win(int DT) { return 0; }
 __host__ __device__ inline int sd_off_wh1(int DT) { return 2 * DT * 1024; }

@@ -106,9 +106,9 @@ SD_INLINE void gelu_tiles(f32x16 (&v)[T]) {
 // `temb` = this step's time embedding [64] (hoisted: the reference recomputes the identical row for
 // every particle, :136-137).
 template <int DT>
-SD_INLINE void mlp_hidden(const f32x16 (&x)[DT], f32x16 (&a)[2], const float* lds, const float* temb, int lane) {
+SD_INLINE void mlp_hidden(const f32x16 (&x)[DT], f32x16 (&a)[2], const float* lds, const float* bias, const float* temb,
+                           int lane) {
   const int h = lane >> 5;
-  const float* bias = lds + sd_off_bias(DT);
   f32x16 b[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) a[t] = load_tile16(bias + 32 * t, h);  // b_in
@@ -130,13 +130,27 @@ SD_INLINE void mlp_hidden(const f32x16 (&x)[DT], f32x16 (&a)[2], const float* ld
 }
 
 template <int DT>
-SD_INLINE f32x16 mlp_out_tile(const f32x16 (&a)[2], const float* lds, int to, int lane) {
+SD_INLINE f32x16 mlp_out_tile(const f32x16 (&a)[2], const float* lds, const float* bias, int to, int lane) {
   const int h = lane >> 5;
   f32x16 u[1];
-  u[0] = load_tile16(lds + sd_off_bias(DT) + 192 + 32 * to, h);  // b_out
+  u[0] = load_tile16(bias + 192 + 32 * to, h);  // b_out
   dense<2, 1>(a, u, lds + sd_off_wout(DT) + to * 2048, lane);
   return u[0];
 }
+
+// ----------------------------------------------------------------------------------------------
+// per-wave reference table in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no VGPR staging).  The copy for
+// step k+1 is issued once the wave has read step k's table for the last time and lands under the next step's
+// MFMA phase; the reader waits with s_waitcnt vmcnt(0) (nothing else orders a ds_read behind an LDS-DMA).
+// ----------------------------------------------------------------------------------------------
+SD_INLINE void dma_table_to_lds(const float* __restrict__ gsrc, float* lds_dst, int n_floats, int lane) {
+  for (int c = 0; c * 256 < n_floats; ++c) {  // 1 KiB per wave-instruction
+    typedef __attribute__((address_space(1))) void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    __builtin_amdgcn_global_load_lds((gvoid*)(gsrc + c * 256 + lane * 4), (lvoid*)(lds_dst + c * 256), 16, 0, 0);
+  }
+}
+SD_INLINE void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ----------------------------------------------------------------------------------------------
 // counter-based noise: Philox4x32-10 + Box-Muller (definition shared with oracle.philox_normal)
@@ -164,11 +178,13 @@ SD_INLINE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 SD_INLINE float u01(uint32_t bits) { return (static_cast<float>(bits >> 9) + 0.5f) * 1.1920928955078125e-07f; }
 
 // normals of features 4*jb .. 4*jb+3 of global particle `pidx` at step `step`.  Counter order
-// (step, jb, pidx, stream): the first round multiplies c0 and c2, so the step product is scalar work and
-// the only loop-invariant per-lane product is the particle's (kept in two registers).
+// (pidx, jb, step, stream): the first round multiplies c0 and c2 and XORs c1 into the c2 product, so the step
+// product is scalar work, the particle product is the only loop-invariant (two registers), and no per-quad
+// partial round can be hoisted out of the step loop (with the step in c0 the compiler hoisted 16 of them
+// per tile and spilled them).
 SD_INLINE f32x4 philox_normal4(uint32_t pidx, uint32_t step, uint32_t jb, uint32_t stream, uint32_t k0, uint32_t k1) {
   uint32_t r[4];
-  philox4x32_10(step, jb, pidx, stream, k0, k1, r);
+  philox4x32_10(pidx, jb, step, stream, k0, k1, r);
   f32x4 z;
   // rad = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u); v_sin/v_cos take revolutions: sin(2 pi u) directly
   const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r[0])));

@@ -40,13 +40,18 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  {  // packed drift-net image -> LDS, once per workgroup
+  {  // packed drift-net weights -> LDS, once per workgroup
     const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    const int n4 = sd_lds_floats(DT) / 4;
+    const int n4 = sd_lds_weight_floats(DT) / 4;
     for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
   }
   __syncthreads();
+  const float* bias = a.wpack + sd_off_bias(DT);
+  // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)
+  constexpr bool ref_lds = (REF == RF_GAUSS || REF == RF_GMM);
+  float* my_tab = lds + sd_lds_weight_floats(DT) + wave * SD_REFTAB_FLOATS;
+  const int tab_floats = a.ref_k * 2 * dpad;
   // Stagger: the two waves that share a SIMD run the same program and would stay in lockstep (both in their
   // MFMA phase, then both in their VALU phase, sharing each pipe in turn).  Delaying the second-dispatched half
   // by about half a step puts one wave's matrix phase beside its partner's vector phase for the whole
@@ -72,6 +77,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       if (a.xs_out) store_rows<DT>(a.xs_out, trash, row, a.d, live, h, x);
     }
 
+    if constexpr (ref_lds) {
+      if (a.N > 0) dma_table_to_lds(a.ref_tab, my_tab, tab_floats, lane);
+    }
     for (int k = 0; k < a.N; ++k) {
       const float* cf = a.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5], c6 = cf[6];
@@ -83,7 +91,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 
       // ---- drift net up to the last hidden activation (FP32 MFMA chain) ----
       f32x16 hid[2];
-      mlp_hidden<DT>(x, hid, lds, a.temb + static_cast<size_t>(k) * SD_H, lane);
+      mlp_hidden<DT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
@@ -92,8 +100,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       if constexpr (SC == SC_PHI4) phi4_score<DT>(x, a.target, d_dyn, h, ts);
       // reference drift (eq/sdes.py:265-279, 329-345): small mixtures keep only the K responsibilities and
       // assemble the score quad by quad in the tail; larger ones use the online-softmax accumulator
-      const float* rtab = a.ref_tab + static_cast<size_t>(k) * a.ref_k * 2 * dpad;
+      const float* rtab = ref_lds ? my_tab : a.ref_tab + static_cast<size_t>(k) * tab_floats;
       const float* rcs = a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2;
+      if constexpr (ref_lds) wait_dma();
       float resp[REF == RF_GMM ? SD_KREG : 1];
       f32x16 rs[REF == RF_GMM_BIG ? DT : 1];
       if constexpr (REF == RF_GMM) gmm_resp<DT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, h, resp);
@@ -106,7 +115,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       float su2 = 0.0f, suz = 0.0f;
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        f32x16 u = mlp_out_tile<DT>(hid, lds, t, lane);
+        // keep the tiles in program order: one 16-register output tile live at a time (the scheduler otherwise
+        // hoists all DT tiles' MFMAs ahead of the vector work and spills)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 u = mlp_out_tile<DT>(hid, lds, bias, t, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float uv = u[r];
@@ -165,6 +177,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
           }
         }
       }
+      if constexpr (ref_lds) {  // next step's table: every read of this step's copy has been consumed above
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < a.N) dma_table_to_lds(a.ref_tab + static_cast<size_t>(k + 1) * tab_floats, my_tab, tab_floats, lane);
+      }
       // running cost 0.5*omega*|u|^2 (losses/oc.py:493) or 0.5*|u|^2*dt (:274); per-step constant
       // (TimeReversalLoss: -int drift divergence, :1218-1219); stochastic integral (:284, :499)
       su2 = half_sum(su2);
@@ -197,10 +213,11 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    const int n4 = sd_lds_floats(DT) / 4;
+    const int n4 = sd_lds_weight_floats(DT) / 4;
     for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
   }
   __syncthreads();
+  const float* bias = a.wpack + sd_off_bias(DT);
   const int p = lane & 31, h = lane >> 5;
   float* trash = a.trash + tid * 4;
   for (int tile = blockIdx.x * SD_WAVES + wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {
@@ -210,7 +227,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
     load_rows<DT>(a.x_in, row, a.d, live, h, x);
     const float score_gain = a.coef[7], lerp_w = a.coef[8];
     f32x16 hid[2];
-    mlp_hidden<DT>(x, hid, lds, a.temb, lane);
+    mlp_hidden<DT>(x, hid, lds, bias, a.temb, lane);
     f32x16 ts[SC != SC_NONE ? DT : 1];
     if constexpr (SC == SC_GMM) gmm_score<DT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, h, ts);
     if constexpr (SC == SC_PHI4) phi4_score<DT>(x, a.target, a.d, h, ts);
@@ -219,7 +236,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
     f32x16 u[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
-      u[t] = mlp_out_tile<DT>(hid, lds, t, lane);
+      u[t] = mlp_out_tile<DT>(hid, lds, bias, t, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float uv = u[t][r];
@@ -235,7 +252,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
 
 template <int DT, int SC>
 static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(sd_lds_floats(DT)) * sizeof(float);
+  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(DT, false));
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_forward<DT, SC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
@@ -251,7 +268,7 @@ typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
 
 template <int DT, int REF, int SC, int FORM, int PAR>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(sd_lds_floats(DT)) * sizeof(float);
+  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(DT, REF == RF_GAUSS || REF == RF_GMM));
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<DT, REF, SC, FORM, PAR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
