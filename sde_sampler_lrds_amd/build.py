@@ -32,7 +32,7 @@ DTS, REFS, SCS, FORMS = (1, 2, 4), (0, 1, 2, 3), (0, 1, 2), (0, 1)
 
 def sources():
     os.makedirs(GEN, exist_ok=True)
-    srcs = [os.path.join(CSRC, "sdeng_api.hip"), os.path.join(CSRC, "prep_kernels.hip")]
+    srcs = [os.path.join(CSRC, "sdeng_api.hip"), os.path.join(CSRC, "prep_kernels.hip"), os.path.join(CSRC, "cmcd_inst.hip")]
     for dt in DTS:
         for rf in REFS:
             for sc in SCS:

@@ -11,6 +11,12 @@
 #include "../../include/sdeng.h"
 #include "prep_kernels.hpp"
 #include "sim_common.hpp"
+#include "cmcd_kernel.hpp"
+
+int sd_launch_cmcd_1(const CmcdArgs& a, int grid, hipStream_t s);
+int sd_launch_cmcd_2(const CmcdArgs& a, int grid, hipStream_t s);
+int sd_launch_logreg_image(const float* X, const float* y, int n, int dw, float* image, float* y_pad, hipStream_t s);
+int sd_launch_pack_square(const float* P, const float* loc, int d, int DT, float* out, float* loc_pad, hipStream_t s);
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
@@ -68,7 +74,7 @@ static size_t dist_floats(const sdeng_dist& ds, int dpad) {
 }
 
 struct Layout {
-  size_t wpack, temb, stheta, ref_tab, ref_consts, target, ref_dist, prior, rnd_init, trash, logz, total;
+  size_t wpack, temb, stheta, ref_tab, ref_consts, target, ref_dist, prior, rnd_init, trash, logz, cmcd, total;
 };
 
 static bool make_layout(const sdeng_desc* d, Layout& L) {
@@ -76,8 +82,8 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   const int DT = tiles_of(d->d), dpad = 32 * DT;
   size_t o = 0;
   L.wpack = o; o += align64(sd_lds_floats(DT));
-  L.temb = o; o += align64(static_cast<size_t>(d->N > 0 ? d->N : 1) * SD_H);
-  L.stheta = o; o += align64(d->N > 0 ? d->N : 1);
+  L.temb = o; o += align64(static_cast<size_t>(d->N + 1) * SD_H);  // CMCD evaluates the net at N+1 times
+  L.stheta = o; o += align64(d->N + 1);
   const int K = d->ref.kind == SDENG_REF_NONE ? 0 : (d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k);
   L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * K * 2 * dpad);
   L.ref_consts = o; o += align64(static_cast<size_t>(d->N) * K * 2);
@@ -87,6 +93,8 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.rnd_init = o; o += align64(d->B);
   L.trash = o; o += align64(SD_THREADS * 4);
   L.logz = o; o += align64(5 * SD_LOGZ_MAX_BLOCKS);
+  L.cmcd = o;
+  if (d->form == SDENG_FORM_CMCD) o += align64(SD_LR_ROWS * SD_LR_STRIDE) + align64(SD_LR_ROWS) + align64(DT * DT * 1024) + align64(32 * DT);
   L.total = o;
   return true;
 }
@@ -222,6 +230,58 @@ static int grid_for(int ntiles) {
   return g < 1 ? 1 : g;
 }
 
+static int grid_for(int ntiles);
+// ControlledLangevinSDELoss.simulate (losses/oc.py:666-755): logistic-regression target, Gaussian prior
+static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s) {
+  const int dpad = 32 * DT;
+  if (DT > 2) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: d <= 64 (got %d)", d->d);
+  if (d->target.kind != SDENG_DIST_LOGREG) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: target must be LOGREG (kind %d)", d->target.kind);
+  if (d->target.k > SD_LR_ROWS) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: at most %d data rows (got %d)", SD_LR_ROWS, d->target.k);
+  if (d->prior.kind != SDENG_DIST_GAUSS_FULL && d->prior.kind != SDENG_DIST_ISO_GAUSS)
+    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: prior must be GAUSS_FULL or ISO_GAUSS (kind %d)", d->prior.kind);
+  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && d->net.ctrl_kind != SDENG_CTRL_SCORE)
+    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: ClippedCtrl or ScoreCtrl");
+  if (!(d->flags & SDENG_FLAG_INIT_LOGP) || !(d->flags & SDENG_FLAG_TERM_TARGET))
+    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel implements the eval path (rnd0 = log p_prior, terminal -log pi)");
+  int rc = prepare_net(d, L, ws, DT, a, s, d->N + 1, false, 0.0f);
+  if (rc) return rc;
+  DistDev target, prior;
+  rc = build_dist(d->target, d->d, dpad, ws + L.target, target, s);
+  if (rc) return rc;
+  rc = build_dist(d->prior, d->d, dpad, ws + L.prior, prior, s);
+  if (rc) return rc;
+  CmcdArgs c;
+  memset(&c, 0, sizeof(c));
+  float* image = ws + L.cmcd;
+  float* y_pad = image + align64(SD_LR_ROWS * SD_LR_STRIDE);
+  float* prec = y_pad + align64(SD_LR_ROWS);
+  float* locp = prec + align64(DT * DT * 1024);
+  SD_HIP(sd_launch_logreg_image(d->target.loc, d->target.scale, d->target.k, d->d - 1, image, y_pad, s));
+  c.x_image = image; c.y_pad = y_pad;
+  c.n_tiles_rows = (d->target.k + 31) / 32;
+  c.w_scale2 = d->target.p0 * d->target.p0; c.c_mean = d->target.p1; c.c_scale2 = d->target.p2 * d->target.p2; c.thr = d->target.p3;
+  if (d->prior.kind == SDENG_DIST_GAUSS_FULL) {
+    SD_HIP(sd_launch_pack_square(d->prior.scale, d->prior.loc, d->d, DT, prec, locp, s));
+    c.prec_pack = prec; c.prior_loc = locp;
+  } else {
+    c.iso_loc = d->prior.p0; c.iso_var = d->prior.p3;
+  }
+  DistEvalArgs e;
+  e.ds = prior; e.B = d->B; e.d = d->d; e.dpad = dpad; e.x = d->x_in; e.logp_out = ws + L.rnd_init; e.score_out = nullptr;
+  SD_HIP(sd_launch_dist_eval(e, s));
+  a.rnd_init = ws + L.rnd_init;
+  a.cmcd_g = d->cmcd_g; a.cmcd_clip = d->cmcd_clip;
+  c.s = a;
+  if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
+  SD_HIP((DT == 1 ? sd_launch_cmcd_1 : sd_launch_cmcd_2)(c, grid_for(a.ntiles), s));
+  if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
+  TerminalArgs t;
+  t.ref = target; t.target = target; t.use_ref = 0; t.use_target = 1;
+  t.B = d->B; t.d = d->d; t.dpad = dpad; t.x = d->x_out; t.rnd = d->rnd_out;
+  SD_HIP(sd_launch_terminal(t, s));
+  return 0;
+}
+
 extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!d) return fail(SDENG_E_INVALID, "null descriptor");
@@ -233,8 +293,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   if (!d->workspace || d->workspace_bytes < L.total * sizeof(float))
     return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, L.total * sizeof(float));
   if (static_cast<long long>(d->B) * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "B*d >= 2^31");
-  if (d->form == SDENG_FORM_CMCD) return fail(SDENG_E_UNSUPPORTED, "FORM_CMCD: kernel not built in this version");
-  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM) return fail(SDENG_E_INVALID, "unknown form %d", d->form);
+  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM && d->form != SDENG_FORM_CMCD) return fail(SDENG_E_INVALID, "unknown form %d", d->form);
   const int DT = tiles_of(d->d), dpad = 32 * DT;
   float* ws = static_cast<float*>(d->workspace);
 
@@ -251,6 +310,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   a.ntiles = (d->B + 31) / 32;
   a.stagger = stagger_units();
 
+  if (d->form == SDENG_FORM_CMCD) return simulate_cmcd(d, L, ws, DT, a, s);
   int rc = prepare_net(d, L, ws, DT, a, s, d->N, false, 0.0f);
   if (rc) return rc;
   int sc;

@@ -444,3 +444,44 @@ SD_INLINE f32x4 load_quad(const float* __restrict__ src, uint32_t row, int d, bo
   }
   return z;
 }
+
+// ----------------------------------------------------------------------------------------------
+// CMCD building blocks (eq/sdes.py:101-110, distr/logistic_regression.py, distr/gauss.py:129-135)
+// ----------------------------------------------------------------------------------------------
+#define SD_LR_ROWS 192      // data rows padded to 6 tiles of 32 (sonar: 166)
+#define SD_LR_STRIDE 65     // LDS row stride of the design-matrix image (odd: conflict-free in both products)
+
+// Dense product whose A operands come from ONE plain LDS image M[rows][SD_LR_STRIDE] (ds_read_b32 per k-step):
+//   TRANS = 0: out[to] += M[32 to + i][feat(ti, r, h)]      (rows = outputs)      logits = X w
+//   TRANS = 1: out[to] += M[feat(ti, r, h)][32 to + i]      (rows = summation)    grad   = X^T r
+// Both address patterns are bank-conflict-free with the odd stride, so the design matrix is stored once.
+template <int TI, int TO, int TRANS>
+SD_INLINE void dense_plain(const f32x16 (&in)[TI], f32x16 (&out)[TO], const float* m, int lane, int in_tile0, int out_tile0) {
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int to = 0; to < TO; ++to)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kf = 32 * (ti + in_tile0) + 8 * (r >> 2) + (r & 3);  // + 4h below
+        const int o = 32 * (to + out_tile0) + i;
+        const float a = TRANS ? m[(kf + 4 * h) * SD_LR_STRIDE + o] : m[o * SD_LR_STRIDE + kf + 4 * h];
+        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[ti][r], out[to], 0, 0, 0);
+      }
+}
+
+// Per-datum factor of the logistic-regression score the reference obtains by autograd through
+// sigmoid -> clip(thr) -> probs_to_logits(clamp eps) -> BCE-with-logits (distr/logistic_regression.py:41-61,
+// distr/base.py:146-154); closed form checked against autograd incl. saturated rows.
+SD_INLINE float logreg_residual(float logit, float y, float thr) {
+  const float eps = 1.1920928955078125e-07f;
+  const float p = 1.0f / (1.0f + expf(-logit));
+  const float pc = fminf(fmaxf(p, thr), 1.0f - thr);
+  const float pcc = fminf(fmaxf(pc, eps), 1.0f - eps);
+  const bool pass = (p >= thr) && (p <= 1.0f - thr) && (pc >= eps) && (pc <= 1.0f - eps);
+  const float l2 = logf(pcc) - log1pf(-pcc);
+  const float sg = 1.0f / (1.0f + expf(-l2));
+  const float r = (y - sg) * (1.0f / pcc + 1.0f / (1.0f - pcc)) * (p * (1.0f - p));
+  return pass ? r : 0.0f;
+}

@@ -264,6 +264,18 @@ def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, alpha=None, si
     'time_reversal' | 'dds'.  ``ts`` is a CPU tensor; every entry is produced by the reference's scalar formula."""
     ts = ts.detach().to("cpu", torch.float32)
     N = ts.numel() - 1
+    if kind == "cmcd":  # N+1 rows: row k holds the times/weights of step k; the last row only ts[N] (net time)
+        out = torch.zeros(N + 1, L.NCOEF, dtype=torch.float32)
+        Tstar = sde.terminal_t
+        for k in range(N + 1):
+            out[k, 0] = ts[k]
+            if k < N:
+                s, t = ts[k], ts[k + 1]
+                dt = t - s
+                out[k, 1], out[k, 2], out[k, 3] = t, dt, dt.sqrt()
+                out[k, 4], out[k, 5] = s / Tstar, 1.0 - s / Tstar  # eq/sdes.py:103
+                out[k, 6], out[k, 7] = t / Tstar, 1.0 - t / Tstar
+        return out
     out = torch.zeros(N, L.NCOEF, dtype=torch.float32)
     T = ts[-1]
     for k in range(N):

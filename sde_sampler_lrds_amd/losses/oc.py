@@ -286,7 +286,40 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
 
     def simulate(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, train=True, change_sde_ctrl=False,
                  return_traj=False, use_ema=False, *, noise=None):
-        raise E.UnsupportedByEngine("the CMCD step kernel (two net + two annealed-score evaluations per step) is not built yet")
+        self._no_train(change_sde_ctrl)
+        if train and self.method in ["kl", "kl_ito"]:
+            raise E.UnsupportedByEngine("CMCD KL-training start (rnd0 = 0) is part of the training direction")
+        if not self.use_rescaling:
+            raise E.UnsupportedByEngine("ControlledLangevinSDELoss(use_rescaling=False) scales the control twice upstream "
+                                        "(losses/oc.py:716-719); not reproduced")
+        E.require_gpu(x)
+        device = x.device
+        keep = []
+        desc = L.Desc()
+        desc.form = L.FORM_CMCD
+        desc.flags = L.FLAG_ITO | L.FLAG_INIT_LOGP | L.FLAG_TERM_TARGET
+        desc.N = ts.numel() - 1
+        desc.seed, desc.particle0 = int(self.seed), int(self.particle0)
+        desc.net = E.net_desc(self._ctrl(use_ema), device, keep)
+        target = getattr(self.sde.target_score, "__self__", None)
+        prior = getattr(self.sde.prior_score, "__self__", None)
+        if target is None or prior is None:
+            raise E.UnsupportedByEngine("ControlledLangevinSDE.target_score / prior_score must be bound Distribution.score methods")
+        res = E.resolve_logp(terminal_unnorm_log_prob)
+        if res is None or res[0] is not target:
+            raise E.UnsupportedByEngine("CMCD: terminal_unnorm_log_prob must be the log-density of sde.target_score's distribution")
+        pr = E.resolve_logp(initial_log_prob) if initial_log_prob is not None else None
+        if pr is None or pr[0] is not prior:
+            raise E.UnsupportedByEngine("CMCD: initial_log_prob must be the log-density of sde.prior_score's distribution")
+        desc.target = E.dist_desc(target, device, keep, clip=res[1])
+        desc.prior = E.dist_desc(prior, device, keep)
+        desc.cmcd_g = float(self.sde.diff_coeff)
+        desc.cmcd_clip = float(self.sde.clip_score) if self.sde.clip_score else 0.0
+        coef = self._coef(ts, device)
+        keep.append(coef)
+        desc.coef = coef.data_ptr()
+        x_out, rnd, xs = E.run(desc, x, keep, return_traj=return_traj, noise=noise, events=self.timing_events)
+        return x_out, rnd, xs
 
 
 class DiscreteTimeReversalLossEI(_InitialLogProbLoss):

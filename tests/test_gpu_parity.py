@@ -11,7 +11,7 @@ from tests import build_cases as bc
 from tests import golden_cases as gc
 
 TOL = 1e-5
-HIP_CASES = [n for n in gc.SIM_CASES if n != "cmcd_logreg_d61"]
+HIP_CASES = list(gc.SIM_CASES)
 
 
 def rnd_scale(c):
