@@ -1,0 +1,122 @@
+"""``make_model`` with the reference's signature (``experiments/benchmark_utils.py:96-265``), without Hydra:
+the YAML constants of ``conf/`` it composes are restated here as dicts, then the same overrides are applied
+and the solver is built (``sde_sampler_lrds_amd.solver.oc``).  Returns an object whose ``evaluate()`` runs the
+HIP engine."""
+from __future__ import annotations
+
+import math
+from functools import partial
+
+import torch
+
+from ..distr.gauss import ManyModes, TwoModes
+from ..distr.phi_four import PhiFour
+from ..solver import oc
+from ..utils.common import get_timesteps
+
+solver_types = {"dds_orig": "dds", "pis_orig": "pis", "dis_orig": "dis", "cmcd": "cmcd", "vp-ref": "vp_rds", "pbm-ref": "pbm_rds"}
+model_types = {"target_informed_zero_init": "score", "target_informed_lerp_tempering": "lerp", "base_zero_init": "basic"}
+
+# conf/solver/*.yaml -> (solver class, prior, sde, default model, default loss)
+_SOLVERS = {
+    "pis": (oc.PIS, dict(kind="delta"), dict(kind="ScaledBM", diff_coeff=math.sqrt(0.2), terminal_t=5.0), "EMReferenceSDELoss"),
+    "dds": (oc.DDS, dict(kind="gauss"), None, "ExponentialIntegratorSDELoss"),
+    "dis": (oc.Bridge, dict(kind="gauss"), dict(kind="VP", diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0), "TimeReversalLoss"),
+    "cmcd": (oc.CMCD, dict(kind="gauss", scale=5.0), dict(kind="ControlledLangevinSDE", diff_coeff=1.0, terminal_t=1.0, clip_score=1e5), "ControlledLangevinSDELoss"),
+    "vp_rds": (oc.RDS, dict(kind="gauss"), dict(kind="VP", diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0), "EMReferenceSDELoss"),
+    "pbm_rds": (oc.RDS, dict(kind="delta"), dict(kind="PinnedBM", diff_coeff=math.sqrt(0.2), terminal_t=5.0), "EMReferenceSDELoss"),
+}
+
+
+def make_target_details(target_name, **kwargs):
+    """experiments/benchmark_utils.py:41-93 (targets with a HIP kernel)."""
+    if target_name == "two_modes":
+        return dict(name=target_name, dim=kwargs.get("dim", 5), ill_conditioned=kwargs.get("ill_conditioned", "medium"), a=kwargs.get("a", 1.0))
+    if target_name == "many_modes":
+        return dict(name="many_modes", dim=kwargs.get("dim", 5), n_modes=kwargs.get("n_modes", 4),
+                    mixture_weight_factor=kwargs.get("mixture_weight_factor", 3.0), var=kwargs.get("var", 0.5))
+    if target_name == "phi_four":
+        return dict(name="phi_four", dim=kwargs.get("dim", 100), b=kwargs.get("b", 0.0))
+    raise NotImplementedError(f"Target {target_name} not supported by the HIP engine.")
+
+
+def _make_target(details):
+    d = dict(details)
+    name = d.pop("name")
+    if name == "many_modes":  # conf/target/many_modes.yaml
+        return ManyModes(**{"n_modes": 4, "dim": 8, "seed_loc": 42, "mixture_weight_factor": 3.0, "var": 0.5, "n_reference_samples": 10000, **d})
+    if name == "two_modes":  # conf/target/two_modes.yaml
+        return TwoModes(**{"dim": 2, "a": 1.0, "n_reference_samples": 10000, **d})
+    if name == "phi_four":  # conf/target/phi_four.yaml
+        return PhiFour(**{"dim": 100, "a": 0.1, "b": 0.0, "dim_phys": 1, "beta": 20.0, **d})
+    if "object" in details:
+        return details["object"]
+    raise NotImplementedError(name)
+
+
+def make_model(solver_type, ref_type, loss_type, integrator_type, model_type, time_type, solver_details, target_details,
+               training_details, optim_details=None, n_steps=100, force_base_zero_init=False, use_ema=False, force_vp20=False,
+               force_vp_cosine=False, compute_samples_based_metrics=True, force_T_cosine=None, device="cuda"):
+    assert solver_type in solver_types and ref_type in ["default", "gaussian", "gmm", "nn"]
+    assert loss_type in ["kl", "lv"] and integrator_type in ["em", "ei", "ddpm_like"] and time_type in ["uniform", "snr"]
+    if model_type not in model_types:
+        raise NotImplementedError(f"model_type {model_type} has no HIP kernel")
+    orig = ("orig" in solver_type) or ("cmcd" in solver_type)
+    if orig and (time_type != "uniform" or integrator_type != "em"):
+        raise ValueError("orig/cmcd solvers: uniform times and the EM integrator only.")
+    if "ref" in solver_type:
+        if solver_type == "pbm-ref" and time_type == "uniform":
+            raise ValueError("PBM schedule is unstable with uniform time discretization.")
+        if integrator_type == "ddpm_like" and time_type == "uniform":
+            raise ValueError("Using the integration scheme from DDPM with uniform times is unstable.")
+    if ref_type != "default" and "ref" not in solver_type and solver_type != "cmcd":
+        raise ValueError("Only ref models can use a non-default ref.")
+    if ref_type == "nn":
+        raise NotImplementedError("'nn' references need autograd per step: no HIP kernel")
+
+    cls, prior, sde, loss_kind = _SOLVERS[solver_types[solver_type]]
+    prior, sde = dict(prior), (dict(sde) if sde else None)
+    if force_vp20 and sde and sde["kind"] == "VP":
+        sde["diff_coeff_sq_max"] = 20.0
+    if force_vp_cosine and sde and sde["kind"] == "VP":
+        sde = dict(kind="CosineVP", c=0.008, scale_diff_coeff=1.0, terminal_t=1.0)
+    loss = dict(kind=loss_kind, method=loss_type, traj_per_sample=1, max_rnd=1e8 if loss_type == "lv" else None)
+    if "ref" in solver_type and integrator_type == "ei":
+        loss["kind"] = "EIReferenceSDELoss"
+    if "ref" in solver_type and integrator_type == "ddpm_like":
+        loss["kind"] = "DDPMLikeReferenceSDELoss"
+    ts = dict(start=0.0, end=sde["terminal_t"] if sde else 6.4, steps=n_steps)
+    if solver_type == "dds_orig":
+        loss.update(alpha=1.0, sigma=solver_details["sigma"])
+        ts = dict(start=0.0, end=force_T_cosine or 6.4, dt=0.05, rescale_t="cosine")
+        prior["scale"] = solver_details["sigma"]
+    elif solver_type == "pis_orig":
+        sde["diff_coeff"] = solver_details["sigma"]
+    elif solver_type == "dis_orig":
+        sde["scale_diff_coeff"] = solver_details["sigma"]
+        prior["scale"] = solver_details["sigma"]
+    elif "ref" in solver_type and ref_type == "default":
+        if "pbm" in solver_type:
+            sde["diff_coeff"] = solver_details["sigma"]
+        else:
+            sde["scale_diff_coeff"] = solver_details["sigma"]
+            prior["scale"] = solver_details["sigma"]
+    if time_type == "snr":
+        ts["start"], ts["end"] = 1e-4, sde["terminal_t"] - 1e-4
+    if force_vp_cosine:
+        ts["start"] = 1e-3
+    cfg = dict(prior=prior, sde=sde, model=model_types[model_type], loss=loss, timesteps=ts,
+               eval_batch_size=training_details["eval_batch_size"], train_batch_size=training_details["train_batch_size"])
+    model = cls(cfg, _make_target(target_details), device=device)
+    if "ref" in solver_type:
+        if ref_type == "gaussian":
+            model.change_reference_type(ref_type="gaussian", mean=solver_details["mean_ref"], var=solver_details["var_ref"])
+        elif ref_type == "gmm":
+            model.change_reference_type(ref_type="gmm", weights=solver_details["weights_ref"], means=solver_details["means_ref"],
+                                        variances=solver_details["variances_ref"])
+    if "cmcd" in solver_type and ref_type == "gaussian":
+        model.update_prior(mean=solver_details["mean"], var=solver_details["var"])
+    if time_type == "snr":
+        model.train_timesteps = partial(get_timesteps, **model.train_timesteps.keywords, sde=model.sde)
+        model.eval_timesteps = model.train_timesteps
+    return model

@@ -1,0 +1,256 @@
+"""Solver objects with the reference's names and evaluation surface (``sde_sampler/solver/oc.py``:
+TrainableDiff :22, Bridge :185, CMCD :264, PIS :349, DDS :426, RDS :495), built from a plain dict instead of
+Hydra (Hydra / OmegaConf are not installable here).  They wire prior / SDE / drift net / loss exactly like the
+reference's ``setup_models`` and expose ``compute_results`` / ``evaluate`` (solver/oc.py:129-182,
+solver/base.py:339-357), ``change_reference_type`` (:513-588), ``update_prior`` (:291-303), ``state_dict``.
+Every ``simulate`` underneath is one HIP launch.  The training loop (``Trainable.step/run``,
+solver/base.py:401-502) is the training direction and is not provided.
+"""
+from __future__ import annotations
+
+import time
+from functools import partial
+
+import torch
+
+from ..distr.delta import Delta
+from ..distr.gauss import Gauss, GaussFull, IsotropicGauss
+from ..eq import sdes
+from ..losses import oc as losses
+from ..models.mlp import FourierMLP, TimeEmbed
+from ..models.reparam import ClippedCtrl, LerpCtrl, ScoreCtrl
+from ..models import utils as mutils
+from ..reference import MarginalReference
+from ..utils.common import Results, clip_and_log, get_timesteps
+
+LOSSES = {name: getattr(losses, name) for name in (
+    "EMReferenceSDELoss", "EIReferenceSDELoss", "DDPMLikeReferenceSDELoss", "ControlledLangevinSDELoss",
+    "DiscreteTimeReversalLossEI", "TimeReversalLoss", "ExponentialIntegratorSDELoss")}
+SDES = {"VP": sdes.VP, "CosineVP": sdes.CosineVP, "ScaledBM": sdes.ScaledBM, "PinnedBM": sdes.PinnedBM,
+        "ControlledLangevinSDE": sdes.ControlledLangevinSDE}
+
+
+def build_ctrl(model: str, dim: int, sde, prior, target):
+    """conf/model/{basic,score,lerp}.yaml + conf/model/base/{fouriermlp,time_embed}.yaml."""
+    act = torch.nn.GELU()
+    net = FourierMLP(dim=dim, activation=act, num_layers=4, channels=64, last_bias_init=mutils.init_bias_uniform_zeros,
+                     last_weight_init=mutils.kaiming_uniform_zeros_)
+    if model == "basic":
+        return ClippedCtrl(base_model=net, clip_model=1e4)
+    bias_init = mutils.init_bias_uniform_zeros if model == "score" else partial(mutils.init_bias_uniform_constant, val=1.0)
+    sm = TimeEmbed(dim_out=1, activation=act, num_layers=4, channels=64, last_bias_init=bias_init,
+                   last_weight_init=mutils.kaiming_uniform_zeros_)
+    common = dict(base_model=net, score_model=sm, target_score=target.score, detach_score=False, clip_score=1e4,
+                  clip_model=1e4, scale_score=1.0)
+    if model == "score":
+        return ScoreCtrl(**common)
+    if model == "lerp":
+        return LerpCtrl(**common, sde=sde, prior_score=prior.score)
+    raise NotImplementedError(f"model '{model}' (langevin_init / unet) has no HIP kernel")
+
+
+class TrainableDiff:
+    """Evaluation half of solver/oc.py:22-182 (+ the parts of solver/base.py it needs)."""
+
+    def __init__(self, cfg: dict, target, device="cuda"):
+        self.cfg, self.target = cfg, target
+        self.device = torch.device(device)
+        self.eval_batch_size = cfg.get("eval_batch_size", 6000)
+        self.train_batch_size = cfg.get("train_batch_size", 512)
+        self.clip_target = cfg.get("clip_target")
+        ts_cfg = dict(cfg["timesteps"])
+        self.train_timesteps = partial(get_timesteps, **ts_cfg)
+        self.eval_timesteps = self.train_timesteps
+        self.eval_ts = None
+        self.use_ema = False
+        self.seed = cfg.get("seed", 1)
+        torch.manual_seed(self.seed)
+        self.setup_models()
+        self.to(self.device)
+
+    # -- wiring ----------------------------------------------------------------------------
+    def make_prior(self):
+        p = self.cfg["prior"]
+        if p["kind"] == "delta":
+            return Delta(dim=self.target.dim)
+        return IsotropicGauss(dim=self.target.dim, scale=p.get("scale", 1.0))
+
+    def make_sde(self, **extra):
+        c = dict(self.cfg["sde"])
+        return SDES[c.pop("kind")](**c, **extra)
+
+    def setup_models(self, langevin_based=False, skip_prior=False):
+        if not skip_prior:
+            self.prior = self.make_prior()
+        if self.cfg.get("sde") is None:
+            self.sde = None
+        elif langevin_based:
+            self.sde = self.make_sde(prior_score=self.prior.score, target_score=self.target.score)
+        else:
+            self.sde = self.make_sde()
+        self.generative_ctrl = build_ctrl(self.cfg["model"], self.target.dim, self.sde, self.prior, self.target)
+        self.generative_ctrl_ema = self.generative_ctrl
+
+    def make_loss(self, **extra):
+        c = dict(self.cfg["loss"])
+        cls = LOSSES[c.pop("kind")]
+        loss = cls(self.generative_ctrl, self.generative_ctrl_ema, sde=self.sde,
+                   filter_samples=getattr(self.target, "filter", None), **c, **extra)
+        loss.seed = self.seed
+        return loss
+
+    def modules(self):
+        return [m for m in (self.target, self.prior, self.sde, self.generative_ctrl, getattr(self, "_reference", None),
+                            getattr(self, "reference_distr", None)) if isinstance(m, torch.nn.Module)]
+
+    def to(self, device):
+        self.device = torch.device(device)
+        for m in self.modules():
+            m.to(self.device)
+        return self
+
+    # -- reference surface -------------------------------------------------------------------
+    def clipped_target_unnorm_log_prob(self, x):
+        return clip_and_log(self.target.unnorm_log_prob(x), max_norm=self.clip_target, name="target")
+
+    def compute_results(self, use_ema=True) -> Results:
+        """solver/oc.py:129-160: one pass with trajectories + weights, one timed pass without."""
+        x = self.prior.sample((self.eval_batch_size,)).to(self.device)
+        if self.eval_ts is None:
+            self.eval_ts = self.eval_timesteps(device=self.device) if self._plain_grid() else self.eval_timesteps().to(self.device)
+        ts = self.eval_ts
+        results = self._compute_results(ts, x, use_ema=use_ema, compute_weights=True)
+        assert results.xs.shape == (len(ts), *results.samples.shape)
+        torch.cuda.synchronize(self.device)
+        start = time.time()
+        extra = self._compute_results(ts, x, use_ema=use_ema, compute_weights=False, return_traj=False)
+        torch.cuda.synchronize(self.device)
+        results.metrics["eval/sample_time"] = time.time() - start
+        results.metrics.update(extra.metrics)
+        results.log_norm_const_preds.update(extra.log_norm_const_preds)
+        return results
+
+    def _plain_grid(self):
+        return "sde" not in self.eval_timesteps.keywords
+
+    @torch.no_grad()
+    def evaluate(self, use_ema=True) -> Results:
+        return self.compute_results(use_ema=use_ema)
+
+    def state_dict(self):
+        return {"generative_ctrl": self.generative_ctrl.state_dict(), "loss": self.loss.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.generative_ctrl.load_state_dict(sd["generative_ctrl"])
+        if "loss" in sd:
+            self.loss.load_state_dict(sd["loss"])
+
+    def step(self, *a, **k):
+        raise NotImplementedError("training loop (solver/base.py:401-457) is not part of this engine (SURVEY.md 8f-1)")
+
+    run = step
+
+
+class _InitialLogProbSolver(TrainableDiff):
+    def _compute_results(self, ts, x, use_ema=True, compute_weights=True, return_traj=True):
+        return self.loss.eval(ts, x, self.clipped_target_unnorm_log_prob, use_ema=use_ema,
+                              initial_log_prob=self.prior.log_prob, compute_weights=compute_weights, return_traj=return_traj)
+
+
+class Bridge(_InitialLogProbSolver):
+    """DIS (solver/oc.py:185-261, without a learned inference control)."""
+
+    def setup_models(self):
+        super().setup_models()
+        if not isinstance(self.prior, Gauss):
+            raise ValueError("Can only be used with Gaussian prior.")
+        self.loss = self.make_loss(**({"inference_ctrl": None} if self.cfg["loss"]["kind"] == "TimeReversalLoss" else {}))
+
+
+class CMCD(_InitialLogProbSolver):
+    """solver/oc.py:264-346."""
+
+    def setup_models(self, skip_prior=False):
+        super().setup_models(langevin_based=True, skip_prior=skip_prior)
+        if not isinstance(self.prior, (Gauss, GaussFull)):
+            raise ValueError("Can only be used with gaussian prior.")
+        self.loss = self.make_loss()
+
+    def update_prior(self, mean, var):
+        dim = mean.shape[0]
+        self.prior = GaussFull(dim=dim, loc=mean, cov=var) if var.dim() == 2 else Gauss(dim=dim, loc=mean, scale=var.sqrt())
+        self.setup_models(skip_prior=True)
+        self.to(self.device)
+
+
+class _ReferenceLogProbSolver(TrainableDiff):
+    def _compute_results(self, ts, x, use_ema=True, compute_weights=True, return_traj=True):
+        return self.loss.eval(ts, x, self.clipped_target_unnorm_log_prob, self.reference_distr.log_prob, use_ema=use_ema,
+                              compute_weights=compute_weights, return_traj=return_traj)
+
+
+class PIS(_ReferenceLogProbSolver):
+    """solver/oc.py:349-423."""
+
+    def setup_models(self):
+        super().setup_models()
+        if not isinstance(self.prior, Delta):
+            raise ValueError("Can only be used with dirac delta prior.")
+        self.reference_distr = self.sde.marginal_distr(t=self.sde.terminal_t, x_init=self.prior.loc)
+        self.loss = self.make_loss()
+
+
+class DDS(_ReferenceLogProbSolver):
+    """solver/oc.py:426-492."""
+
+    def setup_models(self):
+        super().setup_models()
+        if not isinstance(self.prior, Gauss):
+            raise ValueError("Can only be used with Gaussian prior.")
+        self.reference_distr = self.prior
+        self.loss = self.make_loss()
+
+
+class RDS(_ReferenceLogProbSolver):
+    """solver/oc.py:495-666."""
+
+    def setup_models(self):
+        super().setup_models()
+        self.change_reference_type(ref_type="default")
+        self.loss = self.make_loss(reference_ctrl=self.reference_ctrl)
+
+    def change_reference_type(self, ref_type="default", net=None, eps=None, mean=None, var=None, means=None,
+                              variances=None, weights=None):
+        if ref_type == "default":
+            if isinstance(self.sde, sdes.VP):
+                utils = dict(x_init=self.prior.loc.flatten(), var_init=torch.square(self.prior.scale).flatten())
+            elif isinstance(self.sde, sdes.PinnedBM):
+                utils = dict(x_init=self.prior.loc.flatten(),
+                             var_init=(self.sde.terminal_t * self.sde.diff_coeff ** 2 * torch.ones_like(self.prior.loc)).flatten())
+            else:
+                raise ValueError(f"Default reference for SDE type {type(self.sde)} is not supported.")
+            self._reference = MarginalReference(self.sde, "default", **utils)
+        elif ref_type == "gaussian":
+            self._reference = MarginalReference(self.sde, "gaussian", x_init=mean, var_init=var)
+        elif ref_type == "gmm":
+            self._reference = MarginalReference(self.sde, "gmm", means_init=means, variances_init=variances, weights_init=weights)
+        else:
+            raise NotImplementedError(f"Reference type {ref_type}: EBM references need autograd per step (no HIP kernel).")
+        dev = getattr(self, "device", None)
+        if dev is not None:
+            self._reference.to(dev)
+        self.ref_type = ref_type
+        self.reference_distr_utils = self._reference.reference_distr_utils
+        self.reference_distr = self._reference.reference_distr
+        self.reference_score_t = self._reference
+        if hasattr(self, "loss"):
+            self.loss.reference_ctrl = self.reference_ctrl
+
+    def reference_ctrl(self, t, x):
+        return self.reference_score_t(t, x)
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd.update({f"ref_{k}": v for k, v in self.reference_distr_utils.items()})
+        sd["ref_type"] = self.ref_type
+        return sd

@@ -1,0 +1,45 @@
+"""The drop-in driver surface: make_model(...) -> solver.evaluate() on the HIP engine (GPU box)."""
+import pytest
+import torch
+
+from sde_sampler_lrds_amd.experiments.benchmark_utils import make_model, make_target_details
+
+
+def _train(n):
+    return dict(train_steps=1, train_batch_size=64, eval_batch_size=n)
+
+
+@pytest.mark.gpu
+def test_make_model_rds_gmm_evaluate(gpu):
+    tgt = make_target_details("many_modes", dim=16, n_modes=4)
+    K, d = 4, 16
+    g = torch.Generator().manual_seed(0)
+    model = make_model("vp-ref", "gmm", "kl", "ei", "base_zero_init", "uniform",
+                       dict(means_ref=4 * torch.rand(K, d, generator=g) - 2, variances_ref=0.5 * torch.ones(K, d),
+                            weights_ref=torch.ones(K)), tgt, _train(2048), n_steps=32)
+    res = model.evaluate()
+    assert res.samples.shape == (2048, 16) and res.weights.shape == (2048, 1)
+    assert res.xs.shape == (33, 2048, 16)
+    assert abs(res.weights.sum().item() - 1.0) < 1e-4
+    for key in ("eval/elbo", "eval/lv_loss", "eval/sample_time", "eval/norm_effective_sample_size"):
+        assert key in res.metrics
+    assert torch.isfinite(res.samples).all()
+    assert "log_norm_const_is" in res.log_norm_const_preds
+    sd = model.state_dict()
+    assert sd["ref_type"] == "gmm" and "ref_means_init" in sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,ref,integ,mtype,time_type,tname,details", [
+    ("pis_orig", "default", "em", "target_informed_zero_init", "uniform", "phi_four", dict(sigma=0.4472135954999579)),
+    ("dds_orig", "default", "em", "target_informed_zero_init", "uniform", "two_modes", dict(sigma=1.0)),
+    ("dis_orig", "default", "em", "target_informed_lerp_tempering", "uniform", "many_modes", dict(sigma=1.0)),
+    ("vp-ref", "default", "ddpm_like", "base_zero_init", "snr", "many_modes", dict(sigma=1.0)),
+    ("pbm-ref", "default", "ei", "base_zero_init", "snr", "many_modes", dict(sigma=0.4472135954999579)),
+])
+def test_make_model_variants_run(gpu, solver, ref, integ, mtype, time_type, tname, details):
+    tgt = make_target_details(tname, dim=100 if tname == "phi_four" else 8)
+    model = make_model(solver, ref, "lv", integ, mtype, time_type, details, tgt, _train(512), n_steps=16)
+    res = model.evaluate()
+    assert torch.isfinite(res.samples).all() and torch.isfinite(res.weights).all()
+    assert res.samples.shape[0] == 512
