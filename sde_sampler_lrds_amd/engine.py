@@ -398,3 +398,45 @@ def logz_stats(rnd: torch.Tensor, want_weights=True):
     L.check(lib.sdeng_logz(r.data_ptr(), r.numel(), stats.data_ptr(), w.data_ptr() if want_weights else None, ws.data_ptr(),
                            ws.numel(), _stream_ptr(device)))
     return stats, w
+
+
+# ------------------------------------------------------------------------------------------------
+# standalone pieces of the ABI (unit parity tests; also handy for inspection)
+# ------------------------------------------------------------------------------------------------
+def dist_eval(dist, x: torch.Tensor, want_logp=True, want_score=True):
+    """sdeng_dist_eval: log-density [B,1] and score [B,d] of a distribution object, computed in HIP."""
+    require_gpu(x)
+    lib = L.lib()
+    device, keep = x.device, []
+    ds = dist_desc(dist, device, keep)
+    xin = x.detach().to(torch.float32).contiguous()
+    B, d = xin.shape
+    logp = torch.empty(B, 1, dtype=torch.float32, device=device) if want_logp else None
+    score = torch.empty(B, d, dtype=torch.float32, device=device) if want_score else None
+    need = lib.sdeng_dist_workspace_bytes(C.byref(ds), d)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+    L.check(lib.sdeng_dist_eval(C.byref(ds), B, d, xin.data_ptr(), logp.data_ptr() if want_logp else None,
+                                score.data_ptr() if want_score else None, ws.data_ptr(), ws.numel(), _stream_ptr(device)))
+    return logp, score
+
+
+def ctrl_forward(ctrl, t: float, x: torch.Tensor, score_gain=1.0, lerp_w=0.0):
+    """sdeng_ctrl_forward: u = ctrl(t, x) for a ClippedCtrl / ScoreCtrl / LerpCtrl module, computed in HIP."""
+    require_gpu(x)
+    lib = L.lib()
+    device, keep = x.device, []
+    desc = L.Desc()
+    desc.abi_version = L.ABI_VERSION
+    desc.net = net_desc(ctrl, device, keep)
+    tgt, prior = ctrl_target(ctrl)
+    desc.target = dist_desc(tgt, device, keep)
+    desc.prior = dist_desc(prior, device, keep)
+    xin = x.detach().to(torch.float32).contiguous()
+    desc.B, desc.d, desc.N = xin.shape[0], xin.shape[1], 1
+    out = torch.empty_like(xin)
+    need = lib.sdeng_workspace_bytes(C.byref(desc))
+    ws = _WS.get(need, device)
+    desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel()
+    L.check(lib.sdeng_ctrl_forward(C.byref(desc), float(t), float(score_gain), float(lerp_w), xin.data_ptr(), out.data_ptr(),
+                                   _stream_ptr(device)))
+    return out
