@@ -27,7 +27,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fP
 if os.environ.get("SDENG_WAVES"):  # experiment knob: waves per workgroup (8 = 2 per SIMD, 4 = 1 per SIMD)
     FLAGS.append("-DSD_WAVES=" + os.environ["SDENG_WAVES"])
 
-DTS, REFS, SCS, FORMS = (1, 2, 4), (0, 1, 2, 3), (0, 1, 2), (0, 1)
+DTS, REFS, SCS, FORMS = (1, 2, 4, 8), (0, 1, 2, 3), (0, 1, 2), (0, 1)  # DTS: feature tiles of 16
 
 
 def sources():

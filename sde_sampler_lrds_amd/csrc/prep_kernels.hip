@@ -13,39 +13,32 @@
 // ------------------------------------------------------------------------------------------------
 // weights -> packed LDS image.  One thread per packed float.
 // ------------------------------------------------------------------------------------------------
-__device__ inline float pack_fetch(const float* W, int n_out, int n_in, int to, int ti, int r, int lane) {
-  const int o = 32 * to + (lane & 31);
-  const int i = feat(ti, r, lane >> 5);
-  return (o < n_out && i < n_in) ? W[static_cast<size_t>(o) * n_in + i] : 0.0f;
-}
-
 __global__ void k_pack_mlp(PackArgs a) {
-  const int DT = a.DT;
-  const int total = sd_lds_floats(DT);
+  const int NT = a.NT;
+  const int total = sd_pack_floats(NT);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     float v;
-    if (idx < sd_off_bias(DT)) {
-      // which layer
+    if (idx < sd_off_bias(NT)) {
       const float* W;
       int n_out, n_in, TI, local;
-      if (idx < sd_off_wh1(DT)) {
-        W = a.w_in; n_out = SD_H; n_in = a.d; TI = DT; local = idx - sd_off_win(DT);
-      } else if (idx < sd_off_wh2(DT)) {
-        W = a.w_h1; n_out = SD_H; n_in = SD_H; TI = 2; local = idx - sd_off_wh1(DT);
-      } else if (idx < sd_off_wout(DT)) {
-        W = a.w_h2; n_out = SD_H; n_in = SD_H; TI = 2; local = idx - sd_off_wh2(DT);
+      if (idx < sd_off_wh1(NT)) {
+        W = a.w_in; n_out = SD_H; n_in = a.d; TI = NT; local = idx - sd_off_win(NT);
+      } else if (idx < sd_off_wh2(NT)) {
+        W = a.w_h1; n_out = SD_H; n_in = SD_H; TI = SD_HT; local = idx - sd_off_wh1(NT);
+      } else if (idx < sd_off_wout(NT)) {
+        W = a.w_h2; n_out = SD_H; n_in = SD_H; TI = SD_HT; local = idx - sd_off_wh2(NT);
       } else {
-        W = a.w_out; n_out = a.d; n_in = SD_H; TI = 2; local = idx - sd_off_wout(DT);
+        W = a.w_out; n_out = a.d; n_in = SD_H; TI = SD_HT; local = idx - sd_off_wout(NT);
       }
-      // local = (((to*TI + ti)*4 + r4)*64 + lane)*4 + e
-      const int e = local & 3;
+      // local = ((to*TI + ti)*64 + lane)*4 + r  ->  W[16 to + (lane & 15)][feat(ti, r, lane >> 4)]
+      const int r = local & 3;
       const int lane = (local >> 2) & 63;
-      const int r4 = (local >> 8) & 3;
-      const int pair = local >> 10;
+      const int pair = local >> 8;
       const int ti = pair % TI, to = pair / TI;
-      v = pack_fetch(W, n_out, n_in, to, ti, 4 * r4 + e, lane);
+      const int o = 16 * to + (lane & 15), i = feat(ti, r, lane >> 4);
+      v = (o < n_out && i < n_in) ? W[static_cast<size_t>(o) * n_in + i] : 0.0f;
     } else {
-      const int b = idx - sd_off_bias(DT);
+      const int b = idx - sd_off_bias(NT);
       if (b < 64) v = a.b_in[b];
       else if (b < 128) v = a.b_h1[b - 64];
       else if (b < 192) v = a.b_h2[b - 128];
@@ -489,7 +482,7 @@ __global__ void k_philox(unsigned seed_lo, unsigned seed_hi, int step, long long
 
 // ---- host-side launch wrappers -------------------------------------------------------------------
 int sd_launch_pack(const PackArgs& a, hipStream_t s) {
-  const int total = sd_lds_floats(a.DT);
+  const int total = sd_pack_floats(a.NT);
   hipLaunchKernelGGL(k_pack_mlp, dim3((total + 255) / 256), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }

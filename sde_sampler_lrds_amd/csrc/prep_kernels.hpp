@@ -6,7 +6,7 @@
 #define SD_LOGZ_MAX_BLOCKS 1024
 
 struct PackArgs {
-  int DT, d;
+  int NT, d;
   const float *w_in, *b_in, *w_h1, *b_h1, *w_h2, *b_h2, *w_out, *b_out;
   float* out;
 };

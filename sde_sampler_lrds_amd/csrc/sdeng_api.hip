@@ -15,8 +15,9 @@
 
 int sd_launch_cmcd_1(const CmcdArgs& a, int grid, hipStream_t s);
 int sd_launch_cmcd_2(const CmcdArgs& a, int grid, hipStream_t s);
+int sd_launch_cmcd_4(const CmcdArgs& a, int grid, hipStream_t s);
 int sd_launch_logreg_image(const float* X, const float* y, int n, int dw, float* image, float* y_pad, hipStream_t s);
-int sd_launch_pack_square(const float* P, const float* loc, int d, int DT, float* out, float* loc_pad, hipStream_t s);
+int sd_launch_pack_square(const float* P, const float* loc, int d, int NT, float* out, float* loc_pad, hipStream_t s);
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
@@ -30,19 +31,21 @@ typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
 SD_FOR_REF(SD_DECLARE_SIM, 1)
 SD_FOR_REF(SD_DECLARE_SIM, 2)
 SD_FOR_REF(SD_DECLARE_SIM, 4)
+SD_FOR_REF(SD_DECLARE_SIM, 8)
 #define SD_CTRL_ROW(M, DT) M(DT, 0) M(DT, 1) M(DT, 2)
 SD_CTRL_ROW(SD_DECLARE_CTRL, 1)
 SD_CTRL_ROW(SD_DECLARE_CTRL, 2)
 SD_CTRL_ROW(SD_DECLARE_CTRL, 4)
+SD_CTRL_ROW(SD_DECLARE_CTRL, 8)
 
 #define SD_ENTRY(DT, REF, SC, FORM) sd_launch_sim_##DT##_##REF##_##SC##_##FORM,
-static const sim_launch_fn kSimTable[3][4][3][2] = {
+static const sim_launch_fn kSimTable[4][4][3][2] = {
 #define SD_TAB_FORM(DT, REF, SC) {SD_ENTRY(DT, REF, SC, 0) SD_ENTRY(DT, REF, SC, 1)},
 #define SD_TAB_SC(DT, REF) {SD_TAB_FORM(DT, REF, 0) SD_TAB_FORM(DT, REF, 1) SD_TAB_FORM(DT, REF, 2)},
 #define SD_TAB_REF(DT) {SD_TAB_SC(DT, 0) SD_TAB_SC(DT, 1) SD_TAB_SC(DT, 2) SD_TAB_SC(DT, 3)},
-    SD_TAB_REF(1) SD_TAB_REF(2) SD_TAB_REF(4)};
+    SD_TAB_REF(1) SD_TAB_REF(2) SD_TAB_REF(4) SD_TAB_REF(8)};
 #define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
-static const sim_launch_fn kCtrlTable[3][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}};
+static const sim_launch_fn kCtrlTable[4][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}, {SD_CTRL_ROW(SD_CENTRY, 8)}};
 
 // ---- error string ------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -64,8 +67,9 @@ extern "C" const char* sdeng_last_error(void) { return g_err; }
 
 // ---- workspace layout ----------------------------------------------------------------------------
 static inline size_t align64(size_t n_floats) { return (n_floats + 63) & ~static_cast<size_t>(63); }
-static int tiles_of(int d) { return d <= 32 ? 1 : (d <= 64 ? 2 : 4); }
-static int dt_index(int DT) { return DT == 1 ? 0 : (DT == 2 ? 1 : 2); }
+// feature tiles of 16: instantiations exist for 1, 2, 4, 8 tiles (d <= 16, 32, 64, 128)
+static int tiles_of(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 64 ? 4 : 8)); }
+static int dt_index(int NT) { return NT == 1 ? 0 : (NT == 2 ? 1 : (NT == 4 ? 2 : 3)); }
 
 static size_t dist_floats(const sdeng_dist& ds, int dpad) {
   if (ds.kind == SDENG_DIST_GMM_DIAG) return align64(static_cast<size_t>(ds.k) * 2 * dpad) + align64(static_cast<size_t>(ds.k) * 4);
@@ -79,9 +83,9 @@ struct Layout {
 
 static bool make_layout(const sdeng_desc* d, Layout& L) {
   if (!d || d->d < 1 || d->d > 128 || d->N < 0 || d->B < 0) return false;
-  const int DT = tiles_of(d->d), dpad = 32 * DT;
+  const int DT = tiles_of(d->d), dpad = 16 * DT;
   size_t o = 0;
-  L.wpack = o; o += align64(sd_lds_floats(DT));
+  L.wpack = o; o += align64(sd_pack_floats(DT));
   L.temb = o; o += align64(static_cast<size_t>(d->N + 1) * SD_H);  // CMCD evaluates the net at N+1 times
   L.stheta = o; o += align64(d->N + 1);
   const int K = d->ref.kind == SDENG_REF_NONE ? 0 : (d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k);
@@ -94,7 +98,7 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.trash = o; o += align64(SD_THREADS * 4);
   L.logz = o; o += align64(5 * SD_LOGZ_MAX_BLOCKS);
   L.cmcd = o;
-  if (d->form == SDENG_FORM_CMCD) o += align64(SD_LR_ROWS * SD_LR_STRIDE) + align64(SD_LR_ROWS) + align64(DT * DT * 1024) + align64(32 * DT);
+  if (d->form == SDENG_FORM_CMCD) o += align64(SD_LR_ROWS * SD_LR_STRIDE) + align64(SD_LR_ROWS) + align64(DT * DT * 256) + align64(16 * DT);
   L.total = o;
   return true;
 }
@@ -170,7 +174,7 @@ static int prepare_net(const sdeng_desc* d, const Layout& L, float* ws, int DT, 
   int rc = check_net(d->net);
   if (rc) return rc;
   PackArgs pk;
-  pk.DT = DT; pk.d = d->d;
+  pk.NT = DT; pk.d = d->d;
   pk.w_in = d->net.w_in; pk.b_in = d->net.b_in; pk.w_h1 = d->net.w_h1; pk.b_h1 = d->net.b_h1;
   pk.w_h2 = d->net.w_h2; pk.b_h2 = d->net.b_h2; pk.w_out = d->net.w_out; pk.b_out = d->net.b_out;
   pk.out = ws + L.wpack;
@@ -212,29 +216,17 @@ static int score_kind(const sdeng_desc* d, int& sc) {
   return 0;
 }
 
-// start delay of the second half of each workgroup's waves (units of ~8k cycles); SDENG_STAGGER overrides
-static int stagger_units() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SDENG_STAGGER");
-    v = e ? atoi(e) : 4;
-    if (v < 0) v = 0;
-    if (v > 64) v = 64;
-  }
-  return v;
-}
-
 static int grid_for(int ntiles) {
   int g = (ntiles + SD_WAVES - 1) / SD_WAVES;
-  if (g > 256) g = 256;  // one persistent workgroup per CU (LDS image + 2 waves/SIMD fill a CU)
+  if (g > 256) g = 256;  // one persistent workgroup per CU (LDS image + 4 waves/SIMD fill a CU)
   return g < 1 ? 1 : g;
 }
 
 static int grid_for(int ntiles);
 // ControlledLangevinSDELoss.simulate (losses/oc.py:666-755): logistic-regression target, Gaussian prior
 static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s) {
-  const int dpad = 32 * DT;
-  if (DT > 2) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: d <= 64 (got %d)", d->d);
+  const int dpad = 16 * DT;
+  if (DT > 4) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: d <= 64 (got %d)", d->d);
   if (d->target.kind != SDENG_DIST_LOGREG) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: target must be LOGREG (kind %d)", d->target.kind);
   if (d->target.k > SD_LR_ROWS) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: at most %d data rows (got %d)", SD_LR_ROWS, d->target.k);
   if (d->prior.kind != SDENG_DIST_GAUSS_FULL && d->prior.kind != SDENG_DIST_ISO_GAUSS)
@@ -255,10 +247,10 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   float* image = ws + L.cmcd;
   float* y_pad = image + align64(SD_LR_ROWS * SD_LR_STRIDE);
   float* prec = y_pad + align64(SD_LR_ROWS);
-  float* locp = prec + align64(DT * DT * 1024);
+  float* locp = prec + align64(DT * DT * 256);
   SD_HIP(sd_launch_logreg_image(d->target.loc, d->target.scale, d->target.k, d->d - 1, image, y_pad, s));
   c.x_image = image; c.y_pad = y_pad;
-  c.n_tiles_rows = (d->target.k + 31) / 32;
+  c.n_tiles_rows = 2 * ((d->target.k + 31) / 32);  // 16-row tiles, processed in pairs
   c.w_scale2 = d->target.p0 * d->target.p0; c.c_mean = d->target.p1; c.c_scale2 = d->target.p2 * d->target.p2; c.thr = d->target.p3;
   if (d->prior.kind == SDENG_DIST_GAUSS_FULL) {
     SD_HIP(sd_launch_pack_square(d->prior.scale, d->prior.loc, d->d, DT, prec, locp, s));
@@ -273,7 +265,7 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   a.cmcd_g = d->cmcd_g; a.cmcd_clip = d->cmcd_clip;
   c.s = a;
   if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
-  SD_HIP((DT == 1 ? sd_launch_cmcd_1 : sd_launch_cmcd_2)(c, grid_for(a.ntiles), s));
+  SD_HIP((DT == 1 ? sd_launch_cmcd_1 : (DT == 2 ? sd_launch_cmcd_2 : sd_launch_cmcd_4))(c, grid_for(a.ntiles), s));
   if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
   TerminalArgs t;
   t.ref = target; t.target = target; t.use_ref = 0; t.use_target = 1;
@@ -294,7 +286,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, L.total * sizeof(float));
   if (static_cast<long long>(d->B) * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "B*d >= 2^31");
   if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM && d->form != SDENG_FORM_CMCD) return fail(SDENG_E_INVALID, "unknown form %d", d->form);
-  const int DT = tiles_of(d->d), dpad = 32 * DT;
+  const int DT = tiles_of(d->d), dpad = 16 * DT;
   float* ws = static_cast<float*>(d->workspace);
 
   SimArgs a;
@@ -307,8 +299,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   a.coef = d->coef; a.x_in = d->x_in; a.x_out = d->x_out; a.rnd_out = d->rnd_out;
   a.xs_out = d->xs_out; a.noise_in = d->noise_in;
   a.trash = ws + L.trash;
-  a.ntiles = (d->B + 31) / 32;
-  a.stagger = stagger_units();
+  a.ntiles = (d->B + 15) / 16;
 
   if (d->form == SDENG_FORM_CMCD) return simulate_cmcd(d, L, ws, DT, a, s);
   int rc = prepare_net(d, L, ws, DT, a, s, d->N, false, 0.0f);
@@ -321,7 +312,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   int rf = RF_NONE;
   if (d->ref.kind == SDENG_REF_GAUSS_DIAG || d->ref.kind == SDENG_REF_GMM_DIAG) {
     const int K = d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k;
-    rf = d->ref.kind == SDENG_REF_GAUSS_DIAG ? RF_GAUSS : (K <= 4 ? RF_GMM : RF_GMM_BIG);
+    rf = d->ref.kind == SDENG_REF_GAUSS_DIAG ? RF_GAUSS : ((K <= 4 && K * 2 * dpad <= SD_REFTAB_FLOATS) ? RF_GMM : RF_GMM_BIG);
     if (K < 1 || !d->ref.means_init || !d->ref.vars_init) return fail(SDENG_E_INVALID, "reference: null means/vars or k < 1");
     if (d->N > 0) {
       RefTabArgs r;
@@ -382,14 +373,14 @@ extern "C" int sdeng_ctrl_forward(const sdeng_desc* d, float t_net, float score_
   if (!make_layout(d, L)) return fail(SDENG_E_INVALID, "bad sizes");
   if (!d->workspace || d->workspace_bytes < L.total * sizeof(float)) return fail(SDENG_E_WORKSPACE, "workspace too small");
   if (d->B == 0) return 0;
-  const int DT = tiles_of(d->d), dpad = 32 * DT;
+  const int DT = tiles_of(d->d), dpad = 16 * DT;
   float* ws = static_cast<float*>(d->workspace);
   SimArgs a;
   memset(&a, 0, sizeof(a));
   a.B = d->B; a.d = d->d; a.N = 1;
   a.x_in = x; a.x_out = u_out;
   a.trash = ws + L.trash;
-  a.ntiles = (d->B + 31) / 32;
+  a.ntiles = (d->B + 15) / 16;
   int rc = prepare_net(d, L, ws, DT, a, s, 1, true, t_net);
   if (rc) return rc;
   int sc;
@@ -416,7 +407,7 @@ extern "C" int sdeng_dist_eval(const sdeng_dist* dist, int32_t B, int32_t d, con
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!dist || !x || d < 1 || B < 0) return fail(SDENG_E_INVALID, "bad argument");
   if (B == 0) return 0;
-  const int dpad = 32 * ((d + 31) / 32);
+  const int dpad = 16 * ((d + 15) / 16);
   const size_t need = dist_floats(*dist, dpad) * sizeof(float);
   if (need > 0 && (!workspace || workspace_bytes < need)) return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", workspace_bytes, need);
   DistDev dd;
@@ -430,7 +421,7 @@ extern "C" int sdeng_dist_eval(const sdeng_dist* dist, int32_t B, int32_t d, con
 
 extern "C" size_t sdeng_dist_workspace_bytes(const sdeng_dist* dist, int32_t d) {
   if (!dist || d < 1) return 0;
-  return dist_floats(*dist, 32 * ((d + 31) / 32)) * sizeof(float);
+  return dist_floats(*dist, 16 * ((d + 15) / 16)) * sizeof(float);
 }
 
 extern "C" size_t sdeng_logz_workspace_bytes(void) { return 5 * SD_LOGZ_MAX_BLOCKS * sizeof(float); }

@@ -2,57 +2,59 @@
 //
 // Wave-tile layout used by every kernel in this directory
 // --------------------------------------------------------
-// One wavefront (64 lanes) owns a tile of 32 particles.  Lane l holds particle p = l & 31 and the
-// "half" h = l >> 5.  A [32 particles x 32 features] block of state lives in ONE f32x16 register
-// group per lane: register r of lane (p,h) is feature
+// One wavefront (64 lanes) owns a tile of 16 particles.  Lane l holds particle p = l & 15 and the feature
+// group g = l >> 4.  A [16 particles x 16 features] block of state lives in ONE f32x4 register group per lane:
+// register r of lane (p,g) is feature
 //
-//        feat(t, r, h) = 32 t + 8 (r >> 2) + 4 h + (r & 3)           t = feature tile, r = 0..15
+//        feat(t, r, g) = 16 t + 4 g + r                 t = feature tile, r = 0..3
 //
-// which is exactly the C/D layout of v_mfma_f32_32x32x2_f32 when the product is computed as
-// Y^T = W * X^T (rows = output features, columns = particles).  Because an MFMA's summation index is
-// free to be permuted as long as both operands agree, that same register group is directly the
-// B operand of the next layer (k-step r of tile t <-> feature feat(t,r,h)), so the whole
-// [d -> 64 -> 64 -> 64 -> d] drift net runs out of registers with no cross-lane traffic; the A operands
-// (weights) are pre-permuted once into an LDS image by k_pack_mlp.
+// which is exactly the C/D layout of v_mfma_f32_16x16x4_f32 when the product is computed as Y^T = W * X^T
+// (rows = output features, columns = particles).  Because an MFMA's summation index may be permuted as long
+// as both operands agree, that same register group is directly the B operand of the next layer (k-step r of
+// tile t <-> feature feat(t,r,g)), so the whole [d -> 64 -> 64 -> 64 -> d] drift net runs out of registers with
+// no cross-lane traffic; the A operands (weights) are pre-permuted once into an LDS image by k_pack_mlp.
+//
+// Why 16-particle tiles (an earlier build used 32x32x2 MFMA, 32 particles per wave): the state of a tile is
+// half as many registers per lane (d=128: 32 instead of 64), so the kernel fits 4 waves per SIMD instead of 2.
+// PMC counters of the 32-wide build showed the matrix pipe 41 % busy with each wave spending 2.3x as long in
+// vector work and memory waits as in MFMA: two waves per SIMD cannot cover that, four can.  The FP32 MFMA
+// rate is the same for both shapes (64 FLOP/clk/SIMD).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SD_H 64            // hidden channels (models/mlp.py: channels=64)
+#define SD_HT 4            // hidden channel tiles (64 / 16)
 #ifndef SD_WAVES
-#define SD_WAVES 8         // waves per workgroup (2 per SIMD)
+#define SD_WAVES 16        // waves per workgroup (4 per SIMD)
 #endif
 #define SD_THREADS (SD_WAVES * 64)
 
-__host__ __device__ inline int sd_lds_floats(int DT) {
-  // packed image: W_in (2*DT tile pairs) + W_h1 + W_h2 (4 each) + W_out (DT*2), 1024 floats per (out-tile,in-tile)
-  // pair, then b_in, b_h1, b_h2 (64 each) and b_out (32*DT).  The weights live in LDS; the biases are read from
-  // the global copy (a few hundred bytes, L1-resident) so that LDS keeps room for per-wave reference tables.
-  return (2 * DT + 4 + 4 + 2 * DT) * 1024 + 3 * 64 + 32 * DT;
-}
-// per-wave LDS copy of one step's reference table [K][2][dpad]; available while K*2*dpad <= SD_REFTAB_FLOATS
+// packed drift-net image (floats): one (out-tile, in-tile) pair = 16x16 weights = 256 floats
+//   W_in [4][NT] pairs, W_h1 [4][4], W_h2 [4][4], W_out [NT][4]; then b_in, b_h1, b_h2 (64 each), b_out (16*NT)
+__host__ __device__ inline int sd_off_win(int NT) { return 0; }
+__host__ __device__ inline int sd_off_wh1(int NT) { return 4 * NT * 256; }
+__host__ __device__ inline int sd_off_wh2(int NT) { return (4 * NT + 16) * 256; }
+__host__ __device__ inline int sd_off_wout(int NT) { return (4 * NT + 32) * 256; }
+__host__ __device__ inline int sd_lds_weight_floats(int NT) { return (8 * NT + 32) * 256; }
+__host__ __device__ inline int sd_off_bias(int NT) { return sd_lds_weight_floats(NT); }
+__host__ __device__ inline int sd_pack_floats(int NT) { return sd_lds_weight_floats(NT) + 3 * 64 + 16 * NT; }
+// per-wave LDS copy of one step's reference table [K][2][dpad]; used while K*2*dpad <= SD_REFTAB_FLOATS
 #define SD_REFTAB_FLOATS 1024
-__host__ __device__ inline int sd_lds_weight_floats(int DT) { return (4 * DT + 8) * 1024; }
-__host__ __device__ inline int sd_lds_total_bytes(int DT, bool with_ref) {
-  return (sd_lds_weight_floats(DT) + (with_ref ? SD_WAVES * SD_REFTAB_FLOATS : 0)) * 4;
+__host__ __device__ inline int sd_lds_total_bytes(int NT, bool with_ref) {
+  return (sd_lds_weight_floats(NT) + (with_ref ? SD_WAVES * SD_REFTAB_FLOATS : 0)) * 4;
 }
-__host__ __device__ inline int sd_off_win(int DT) { return 0; }
-__host__ __device__ inline int sd_off_wh1(int DT) { return 2 * DT * 1024; }
-__host__ __device__ inline int sd_off_wh2(int DT) { return (2 * DT + 4) * 1024; }
-__host__ __device__ inline int sd_off_wout(int DT) { return (2 * DT + 8) * 1024; }
-__host__ __device__ inline int sd_off_bias(int DT) { return (4 * DT + 8) * 1024; }
 
 // device-side view of a distribution (tables prepared by k_dist_tables)
 struct DistDev {
   int kind;
   int k;
-  const float* tab;     // GMM/GAUSS_DIAG: [k][2][dpad]  (mean, 1/var)
-  const float* consts;  // GMM/GAUSS_DIAG: [k][2]  (sum log sigma + d*log sqrt(2pi), log mixture prob)
-  const float* aux0;    // LOGREG: packed X images; GAUSS_FULL: packed precision / L^-1 images
-  const float* aux1;
+  const float* tab;     // GMM/GAUSS_DIAG: [k][2][dpad]  (mean, 1/var); GAUSS_FULL: precision [d,d]
+  const float* consts;  // GMM/GAUSS_DIAG: [k][4]
+  const float* aux0;    // LOGREG: X; GAUSS_FULL: loc
+  const float* aux1;    // LOGREG: y; GAUSS_FULL: L^-1
   float p0, p1, p2, p3;
   float clip;
 };
@@ -69,7 +71,7 @@ struct SimArgs {
   float* rnd_out;
   float* xs_out;
   const float* noise_in;
-  const float* wpack;     // packed MLP LDS image (global copy)
+  const float* wpack;     // packed drift-net image (global copy)
   const float* temb;      // [N][64] time embedding of the drift net, per step
   const float* stheta;    // [N] clipped score_model(t) or nullptr
   int ctrl_kind;
@@ -83,6 +85,5 @@ struct SimArgs {
   const float* rnd_init;  // [B] initial log-weight (log p_prior(x0)) or nullptr
   float* trash;           // [SD_THREADS*4] dump slots for masked stores
   float cmcd_g, cmcd_clip;
-  int ntiles;
-  int stagger;            // start delay of waves 4..7, in units of s_sleep(127) (~8k cycles): see k_simulate
+  int ntiles;             // ceil(B / 16)
 };

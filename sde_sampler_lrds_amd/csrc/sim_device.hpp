@@ -8,9 +8,13 @@
 // ----------------------------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------------------------
-// The two lanes p and p+32 hold the two feature-halves of one particle: one cross-half add finishes
+// The four lanes p, p+16, p+32, p+48 hold the four feature groups of one particle: two cross-lane adds finish
 // every per-particle reduction (log-weight increments, mixture logits).
-SD_INLINE float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+SD_INLINE float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
 
 // torch.clip semantics: NaN stays NaN (fminf/fmaxf or v_med3 would swallow it).
 SD_INLINE float clampf(float v, float m) {
@@ -47,95 +51,76 @@ SD_INLINE float erf_bf(float a) {
 // exact-erf GELU, torch's CPU formula (x*0.5)*(1+erf(x/sqrt2))  -- models/mlp.py activation nn.GELU()
 SD_INLINE float gelu(float v) { return (v * 0.5f) * (1.0f + erf_bf(v * 0.70710678118654752440f)); }
 
-SD_INLINE int feat(int t, int r, int h) { return 32 * t + 8 * (r >> 2) + 4 * h + (r & 3); }
-// feat(t, r, h) < d with the lane-dependent part (4h) on one side only: the compare takes a scalar
-// operand, so no per-element index register is ever materialised.
-SD_INLINE bool feat_lt(int t, int r, int h4, int d) { return h4 < d - (32 * t + 8 * (r >> 2) + (r & 3)); }
+SD_INLINE int feat(int t, int r, int g) { return 16 * t + 4 * g + r; }
+// feat(t, r, g) < d with the lane-dependent part (4g) on one side only: the compare takes a scalar operand,
+// so no per-element index register is ever materialised.
+SD_INLINE bool feat_lt(int t, int r, int g4, int d) { return g4 < d - (16 * t + r); }
 
-// 16 registers of one feature tile for this lane from a dense [..] vector (tile base = 32*t)
-SD_INLINE f32x16 load_tile16(const float* base, int h) {
-  f32x16 v;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 b = *reinterpret_cast<const f32x4*>(base + 8 * q + 4 * h);
-    v[4 * q + 0] = b.x;
-    v[4 * q + 1] = b.y;
-    v[4 * q + 2] = b.z;
-    v[4 * q + 3] = b.w;
-  }
-  return v;
-}
+// the 4 registers of feature tile t for this lane from a dense vector
+SD_INLINE f32x4 load_tile4(const float* base, int t, int g) { return *reinterpret_cast<const f32x4*>(base + 16 * t + 4 * g); }
 
 // ----------------------------------------------------------------------------------------------
 // FP32 MFMA dense layer:  out[to] += W[to-tile][ti-tile] * in[ti]   (Y^T = W X^T form)
-// `w` is the LDS image written by k_pack_mlp: float4 index ((to*TI+ti)*4+r4)*64+lane holds the A
-// operands of k-steps r = 4*r4 .. 4*r4+3, i.e. W[32 to + (lane&31)][feat(ti, r, lane>>5)].
-// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (1e-5 parity rules out bf16/xf32 paths).
+// `w` is the LDS image written by k_pack_mlp: float4 index (to*TI+ti)*64+lane holds the A operands of the four
+// k-steps of that tile pair, W[16 to + (lane&15)][feat(ti, r, lane>>4)], r = 0..3.
+// v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain (1e-5 parity rules out bf16/xf32 paths); consecutive MFMAs
+// go to different accumulators (dependent latency 40 cycles vs 32-cycle issue).
 // ----------------------------------------------------------------------------------------------
 template <int TI, int TO>
-SD_INLINE void dense(const f32x16 (&in)[TI], f32x16 (&out)[TO], const float* w, int lane) {
+SD_INLINE void dense(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* w, int lane) {
   const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
 #pragma unroll
-  for (int to = 0; to < TO; ++to) {
+  for (int ti = 0; ti < TI; ++ti) {
+    f32x4 a[TO];
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) {
+    for (int to = 0; to < TO; ++to) a[to] = w4[(to * TI + ti) * 64 + lane];
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const f32x4 a = w4[((to * TI + ti) * 4 + r4) * 64 + lane];
-        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, in[ti][4 * r4 + 0], out[to], 0, 0, 0);
-        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, in[ti][4 * r4 + 1], out[to], 0, 0, 0);
-        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, in[ti][4 * r4 + 2], out[to], 0, 0, 0);
-        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, in[ti][4 * r4 + 3], out[to], 0, 0, 0);
-      }
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int to = 0; to < TO; ++to) out[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to][r], in[ti][r], out[to], 0, 0, 0);
   }
 }
 
 template <int T>
-SD_INLINE void gelu_tiles(f32x16 (&v)[T]) {
+SD_INLINE void gelu_tiles(f32x4 (&v)[T]) {
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[t][r] = gelu(v[t][r]);
+    for (int r = 0; r < 4; ++r) v[t][r] = gelu(v[t][r]);
 }
 
-// FourierMLP.forward (models/mlp.py:135-143) for a 32-particle tile, split in two so that the d-wide
-// output never has to be live at once: mlp_hidden() runs input_embed + time embedding + the two hidden
-// layers and returns gelu(h) (64 channels = 2 register tiles); mlp_out_tile() produces ONE 32-feature
-// tile of out_layer, which the caller consumes (clip, cost, integrator) before asking for the next.
-// `temb` = this step's time embedding [64] (hoisted: the reference recomputes the identical row for
-// every particle, :136-137).
-template <int DT>
-SD_INLINE void mlp_hidden(const f32x16 (&x)[DT], f32x16 (&a)[2], const float* lds, const float* bias, const float* temb,
-                           int lane) {
-  const int h = lane >> 5;
-  f32x16 b[2];
+// FourierMLP.forward (models/mlp.py:135-143) for a 16-particle tile, split in two so that the d-wide output
+// never has to be live at once: mlp_hidden() runs input_embed + time embedding + the two hidden layers and
+// returns gelu(h) (64 channels = 4 register tiles); mlp_out_tiles() produces OT 16-feature tiles of out_layer,
+// which the caller consumes (clip, cost, integrator) before asking for the next.  `temb` = this step's time
+// embedding [64] (hoisted: the reference recomputes the identical row for every particle, :136-137).
+template <int NT>
+SD_INLINE void mlp_hidden(const f32x4 (&x)[NT], f32x4 (&a)[SD_HT], const float* lds, const float* bias, const float* temb,
+                          int lane) {
+  const int g = lane >> 4;
+  f32x4 b[SD_HT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) a[t] = load_tile16(bias + 32 * t, h);  // b_in
-  dense<DT, 2>(x, a, lds + sd_off_win(DT), lane);
+  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias, t, g);  // b_in
+  dense<NT, SD_HT>(x, a, lds + sd_off_win(NT), lane);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {  // embed = embed_x + embed_t
-    const f32x16 e = load_tile16(temb + 32 * t, h);
-    a[t] = a[t] + e;
-  }
-  gelu_tiles<2>(a);
+  for (int t = 0; t < SD_HT; ++t) a[t] = a[t] + load_tile4(temb, t, g);  // embed = embed_x + embed_t
+  gelu_tiles<SD_HT>(a);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) b[t] = load_tile16(bias + 64 + 32 * t, h);  // b_h1
-  dense<2, 2>(a, b, lds + sd_off_wh1(DT), lane);
-  gelu_tiles<2>(b);
+  for (int t = 0; t < SD_HT; ++t) b[t] = load_tile4(bias + 64, t, g);  // b_h1
+  dense<SD_HT, SD_HT>(a, b, lds + sd_off_wh1(NT), lane);
+  gelu_tiles<SD_HT>(b);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) a[t] = load_tile16(bias + 128 + 32 * t, h);  // b_h2
-  dense<2, 2>(b, a, lds + sd_off_wh2(DT), lane);
-  gelu_tiles<2>(a);
+  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias + 128, t, g);  // b_h2
+  dense<SD_HT, SD_HT>(b, a, lds + sd_off_wh2(NT), lane);
+  gelu_tiles<SD_HT>(a);
 }
 
-template <int DT>
-SD_INLINE f32x16 mlp_out_tile(const f32x16 (&a)[2], const float* lds, const float* bias, int to, int lane) {
-  const int h = lane >> 5;
-  f32x16 u[1];
-  u[0] = load_tile16(bias + 192 + 32 * to, h);  // b_out
-  dense<2, 1>(a, u, lds + sd_off_wout(DT) + to * 2048, lane);
-  return u[0];
+template <int NT, int OT>
+SD_INLINE void mlp_out_tiles(const f32x4 (&a)[SD_HT], const float* lds, const float* bias, int t0, int lane, f32x4 (&u)[OT]) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int o = 0; o < OT; ++o) u[o] = load_tile4(bias + 192, t0 + o, g);  // b_out
+  dense<SD_HT, OT>(a, u, lds + sd_off_wout(NT) + t0 * SD_HT * 256, lane);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -180,8 +165,7 @@ SD_INLINE float u01(uint32_t bits) { return (static_cast<float>(bits >> 9) + 0.5
 // normals of features 4*jb .. 4*jb+3 of global particle `pidx` at step `step`.  Counter order
 // (pidx, jb, step, stream): the first round multiplies c0 and c2 and XORs c1 into the c2 product, so the step
 // product is scalar work, the particle product is the only loop-invariant (two registers), and no per-quad
-// partial round can be hoisted out of the step loop (with the step in c0 the compiler hoisted 16 of them
-// per tile and spilled them).
+// partial round can be hoisted out of the step loop.
 SD_INLINE f32x4 philox_normal4(uint32_t pidx, uint32_t step, uint32_t jb, uint32_t stream, uint32_t k0, uint32_t k1) {
   uint32_t r[4];
   philox4x32_10(pidx, jb, step, stream, k0, k1, r);
@@ -198,96 +182,76 @@ SD_INLINE f32x4 philox_normal4(uint32_t pidx, uint32_t step, uint32_t jb, uint32
 }
 
 // ----------------------------------------------------------------------------------------------
-// Gaussian-mixture score (distr/gauss.py:97-107 score_mog) with an online softmax over components.
+// Gaussian-mixture score (distr/gauss.py:97-107 score_mog).
 // tab: [K][2][dpad] (mean, 1/var); consts: [K][cstride] with [0] = 0.5*sum log var, [1] = log w_k.
 // ----------------------------------------------------------------------------------------------
-template <int DT>
-SD_INLINE void gmm_score(const f32x16 (&x)[DT], const float* __restrict__ tab, const float* __restrict__ consts,
-                         int cstride, int K, float c1, int h, f32x16 (&acc)[DT]) {
-  constexpr int dpad = 32 * DT;
+// component logit: log w_k + log N(x; m_k, v_k)   (distr/gauss.py:70-72, :103)
+template <int NT>
+SD_INLINE float gmm_logit(const f32x4 (&x)[NT], const float* __restrict__ tab, const float* __restrict__ consts, int cstride,
+                          int k, float c1, int g) {
+  constexpr int dpad = 16 * NT;
+  const float* mp = tab + static_cast<size_t>(k) * 2 * dpad;
+  float part = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 m = load_tile4(mp, t, g);
+    const f32x4 iv = load_tile4(mp + dpad, t, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dl = x[t][r] - m[r];
+      part = __builtin_fmaf(dl * dl, iv[r], part);
+    }
+  }
+  part = group_sum(part);
+  const float v = ((-0.5f * part) - c1) - consts[k * cstride + 0];
+  return consts[k * cstride + 1] + v;
+}
+
+// any K: online softmax over components, score accumulated in a d-wide register array
+template <int NT>
+SD_INLINE void gmm_score(const f32x4 (&x)[NT], const float* __restrict__ tab, const float* __restrict__ consts,
+                         int cstride, int K, float c1, int g, f32x4 (&acc)[NT]) {
+  constexpr int dpad = 16 * NT;
   float m_run = -INFINITY, l_run = 0.0f;
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   for (int k = 0; k < K; ++k) {
-    const float* mp = tab + static_cast<size_t>(k) * 2 * dpad + 4 * h;
-    const float* vp = mp + dpad;
-    float part = 0.0f;
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(mp + 32 * t + 8 * q);
-        const f32x4 iv = *reinterpret_cast<const f32x4*>(vp + 32 * t + 8 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float dl = x[t][4 * q + e] - m[e];
-          part = __builtin_fmaf(dl * dl, iv[e], part);
-        }
-      }
-    part = half_sum(part);
-    float lp = ((-0.5f * part) - c1) - consts[k * cstride + 0];  // distr/gauss.py:70-72
-    lp = consts[k * cstride + 1] + lp;                           // torch.log(weights) + log_prob
+    const float lp = gmm_logit<NT>(x, tab, consts, cstride, k, c1, g);
     const float m_new = fmaxf(m_run, lp);
     const float so = expf(m_run - m_new);
     const float pk = expf(lp - m_new);
     l_run = l_run * so + pk;
     m_run = m_new;
+    const float* mp = tab + static_cast<size_t>(k) * 2 * dpad;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 m = load_tile4(mp, t, g);
+      const f32x4 iv = load_tile4(mp + dpad, t, g);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(mp + 32 * t + 8 * q);
-        const f32x4 iv = *reinterpret_cast<const f32x4*>(vp + 32 * t + 8 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = (m[e] - x[t][4 * q + e]) * iv[e];  // -(x - mean)/var
-          acc[t][4 * q + e] = __builtin_fmaf(pk, g, acc[t][4 * q + e] * so);
-        }
-      }
+      for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(pk, (m[r] - x[t][r]) * iv[r], acc[t][r] * so);  // -(x-mean)/var
+    }
   }
   const float inv = 1.0f / l_run;
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
+  for (int t = 0; t < NT; ++t) acc[t] = acc[t] * inv;
 }
 
-// Small-mixture variant (K <= SD_KREG; the reference's default n_modes is 4, conf/target/many_modes.yaml): component responsibilities p_k = softmax_k(log w_k + log N_k(x)) are
-// computed once (pass 1) and kept in registers; the score of a feature is then assembled where it is
-// consumed, sum_k p_k (m_k - x) / var_k, so no d-wide score array stays live across the output layer.
+// Small-mixture variant (K <= SD_KREG; the reference's default n_modes is 4, conf/target/many_modes.yaml):
+// component responsibilities p_k = softmax_k(logit_k) are computed once and kept in registers; the score of a
+// feature tile is then assembled where it is consumed, sum_k p_k (m_k - x) / var_k, so no d-wide score array
+// stays live across the output layer.
 #define SD_KREG 4
-template <int DT>
-SD_INLINE void gmm_resp(const f32x16 (&x)[DT], const float* __restrict__ tab, const float* __restrict__ consts,
-                        int cstride, int K, float c1, int h, float (&p)[SD_KREG]) {
-  constexpr int dpad = 32 * DT;
+template <int NT>
+SD_INLINE void gmm_resp(const f32x4 (&x)[NT], const float* __restrict__ tab, const float* __restrict__ consts,
+                        int cstride, int K, float c1, int g, float (&p)[SD_KREG]) {
   float lp[SD_KREG];
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < SD_KREG; ++k) {
     lp[k] = -INFINITY;
     if (k < K) {
-      const float* mp = tab + static_cast<size_t>(k) * 2 * dpad + 4 * h;
-      const float* vp = mp + dpad;
-      float part = 0.0f;
-#pragma unroll
-      for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(mp + 32 * t + 8 * q);
-          const f32x4 iv = *reinterpret_cast<const f32x4*>(vp + 32 * t + 8 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float dl = x[t][4 * q + e] - m[e];
-            part = __builtin_fmaf(dl * dl, iv[e], part);
-          }
-        }
-      part = half_sum(part);
-      float v = ((-0.5f * part) - c1) - consts[k * cstride + 0];  // distr/gauss.py:70-72
-      v = consts[k * cstride + 1] + v;                           // torch.log(weights) + log_prob
-      lp[k] = v;
-      mx = fmaxf(mx, v);
+      lp[k] = gmm_logit<NT>(x, tab, consts, cstride, k, c1, g);
+      mx = fmaxf(mx, lp[k]);
     }
   }
   float den = 0.0f;
@@ -301,173 +265,142 @@ SD_INLINE void gmm_resp(const f32x16 (&x)[DT], const float* __restrict__ tab, co
   for (int k = 0; k < SD_KREG; ++k) p[k] *= inv;
 }
 
-// score of the four features of quad (t, q) from the responsibilities: -sum_k p_k (x - m_k)/var_k
-template <int DT>
-SD_INLINE f32x4 gmm_score_quad(const f32x16 (&x)[DT], const float* __restrict__ tab, int K, int h, const float (&p)[SD_KREG],
-                               int t, int q) {
-  constexpr int dpad = 32 * DT;
+template <int NT>
+SD_INLINE f32x4 gmm_score_tile(const f32x4 (&x)[NT], const float* __restrict__ tab, int K, int g, const float (&p)[SD_KREG], int t) {
+  constexpr int dpad = 16 * NT;
   f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < SD_KREG; ++k) {
     if (k < K) {
-      const float* mp = tab + static_cast<size_t>(k) * 2 * dpad + 4 * h + 32 * t + 8 * q;
-      const f32x4 m = *reinterpret_cast<const f32x4*>(mp);
-      const f32x4 iv = *reinterpret_cast<const f32x4*>(mp + dpad);
+      const float* mp = tab + static_cast<size_t>(k) * 2 * dpad;
+      const f32x4 m = load_tile4(mp, t, g);
+      const f32x4 iv = load_tile4(mp + dpad, t, g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(p[k], (m[e] - x[t][4 * q + e]) * iv[e], acc[e]);
+      for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(p[k], (m[r] - x[t][r]) * iv[r], acc[r]);
     }
   }
   return acc;
 }
 
-// Gaussian (one component) score: -(x - mean)/var  (distr/gauss.py:124-126)
-template <int DT>
-SD_INLINE void gauss_score(const f32x16 (&x)[DT], const float* __restrict__ tab, int h, f32x16 (&acc)[DT]) {
-  constexpr int dpad = 32 * DT;
-  const float* mp = tab + 4 * h;
-  const float* vp = mp + dpad;
+// Gaussian (one component) score of one tile: -(x - mean)/var  (distr/gauss.py:124-126)
+template <int NT>
+SD_INLINE f32x4 gauss_score_tile(const f32x4 (&x)[NT], const float* __restrict__ tab, int g, int t) {
+  constexpr int dpad = 16 * NT;
+  const f32x4 m = load_tile4(tab, t, g);
+  const f32x4 iv = load_tile4(tab + dpad, t, g);
+  f32x4 out;
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 m = *reinterpret_cast<const f32x4*>(mp + 32 * t + 8 * q);
-      const f32x4 iv = *reinterpret_cast<const f32x4*>(vp + 32 * t + 8 * q);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = -((x[t][4 * q + e] - m[e]) * iv[e]);
-    }
+  for (int r = 0; r < 4; ++r) out[r] = -((x[t][r] - m[r]) * iv[r]);
+  return out;
 }
 
-// phi^4 lattice neighbours of one group of four features (g = 4 t + q; features 8 g + 4 h + 0..3).
-// The partner lane (p, 1-h) holds the sites adjacent to the group's two ends; 0 outside the lattice.
-template <int DT>
-SD_INLINE void phi4_group_edges(const f32x16 (&x)[DT], int g, int h, float& l_edge, float& r_edge) {
-  const int t = g >> 2, q = g & 3;
-  const float p3 = __shfl_xor(x[t][4 * q + 3], 32, 64);  // partner's last site of group g
-  const float p0 = __shfl_xor(x[t][4 * q + 0], 32, 64);  // partner's first site of group g
-  float p3prev = 0.0f, p0next = 0.0f;
-  if (g > 0) p3prev = __shfl_xor(x[(g - 1) >> 2][4 * ((g - 1) & 3) + 3], 32, 64);
-  if (g < 4 * DT - 1) p0next = __shfl_xor(x[(g + 1) >> 2][4 * ((g + 1) & 3) + 0], 32, 64);
-  l_edge = h ? p3 : p3prev;  // h==0: site 8g-1 is (g-1, e=3, h=1); h==1: site 8g+3 is (g, e=3, h=0)
-  r_edge = h ? p0next : p0;  // h==0: site 8g+4 is (g, e=0, h=1); h==1: site 8g+8 is (g+1, e=0, h=0)
+// phi^4 lattice neighbours of tile t (sites 16 t + 4 g + 0..3).  Lane (p, g-1) holds the site left of the
+// group, lane (p, g+1) the site right of it; across a tile border they come from the neighbouring tile.
+template <int NT>
+SD_INLINE void phi4_edges(const f32x4 (&x)[NT], int t, int g, int lane, float& l_edge, float& r_edge) {
+  const int up = (lane + 48) & 63, dn = (lane + 16) & 63;  // lanes (p, g-1) and (p, g+1), wrapping
+  const float l_same = __shfl(x[t][3], up, 64);
+  const float r_same = __shfl(x[t][0], dn, 64);
+  float l_prev = 0.0f, r_next = 0.0f;
+  if (t > 0) l_prev = __shfl(x[t > 0 ? t - 1 : 0][3], up, 64);            // g == 0: site 16t-1 = (t-1, r=3, g=3)
+  if (t < NT - 1) r_next = __shfl(x[t < NT - 1 ? t + 1 : t][0], dn, 64);  // g == 3: site 16t+16 = (t+1, r=0, g=0)
+  l_edge = (g == 0) ? l_prev : l_same;
+  r_edge = (g == 3) ? r_next : r_same;
 }
 
 // PhiFour.score = -beta * grad_U  (distr/phi_four.py:81-96); p0=a, p1=b, p2=beta
-template <int DT>
-SD_INLINE void phi4_score(const f32x16 (&x)[DT], const DistDev& ds, int d, int h, f32x16 (&acc)[DT]) {
+template <int NT>
+SD_INLINE void phi4_score(const f32x4 (&x)[NT], const DistDev& ds, int d, int g, int lane, f32x4 (&acc)[NT]) {
   const float coef = ds.p0 * static_cast<float>(d);
 #pragma unroll
-  for (int g = 0; g < 4 * DT; ++g) {
-    const int t = g >> 2, q = g & 3;
+  for (int t = 0; t < NT; ++t) {
     float le, re;
-    phi4_group_edges<DT>(x, g, h, le, re);
+    phi4_edges<NT>(x, t, g, lane, le, re);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xv = x[t][4 * q + e];
-      const float xl = (e == 0) ? le : x[t][4 * q + (e > 0 ? e - 1 : 0)];
-      const float xr = (e == 3) ? re : x[t][4 * q + (e < 3 ? e + 1 : 3)];
+    for (int r = 0; r < 4; ++r) {
+      const float xv = x[t][r];
+      const float xl = (r == 0) ? le : x[t][r > 0 ? r - 1 : 0];
+      const float xr = (r == 3) ? re : x[t][r < 3 ? r + 1 : 3];
       float gr = (ds.p1 - xv * (1.0f - xv * xv)) / coef;
       gr = gr + coef * ((2.0f * xv - xr) - xl);
-      acc[t][4 * q + e] = feat_lt(t, 4 * q + e, 4 * h, d) ? (-ds.p2) * gr : 0.0f;
+      acc[t][r] = feat_lt(t, r, 4 * g, d) ? (-ds.p2) * gr : 0.0f;
     }
   }
 }
 
+// ----------------------------------------------------------------------------------------------
 // Tile-row I/O without control flow: masked lanes (dead rows, pad features) read element 0 of the array
 // and discard it, or write to a per-lane dump slot (`trash`, 4 floats per lane) instead of the array.
 // Only trajectory start/end, injected noise (parity mode) and trajectory dumps come through here.
-template <int DT>
-SD_INLINE void load_rows(const float* __restrict__ src, uint32_t row, int d, bool live, int h, f32x16 (&v)[DT]) {
-  const size_t base = static_cast<size_t>(row) * d;
-  if ((d & 3) == 0) {
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool ok = live && feat_lt(t, 4 * q, 4 * h, d);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(src + (ok ? base + (32 * t + 8 * q + 4 * h) : 0));
-        v[t][4 * q + 0] = ok ? b.x : 0.0f;
-        v[t][4 * q + 1] = ok ? b.y : 0.0f;
-        v[t][4 * q + 2] = ok ? b.z : 0.0f;
-        v[t][4 * q + 3] = ok ? b.w : 0.0f;
-      }
-  } else {
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = live && feat_lt(t, r, 4 * h, d);
-        const float b = src[ok ? base + feat(t, r, h) : 0];
-        v[t][r] = ok ? b : 0.0f;
-      }
-  }
-}
-
-template <int DT>
-SD_INLINE void store_rows(float* __restrict__ dst, float* __restrict__ trash, uint32_t row, int d, bool live, int h,
-                          const f32x16 (&v)[DT]) {
-  const size_t base = static_cast<size_t>(row) * d;
-  if ((d & 3) == 0) {
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool ok = live && feat_lt(t, 4 * q, 4 * h, d);
-        f32x4 b;
-        b.x = v[t][4 * q + 0];
-        b.y = v[t][4 * q + 1];
-        b.z = v[t][4 * q + 2];
-        b.w = v[t][4 * q + 3];
-        float* pdst = ok ? dst + base + (32 * t + 8 * q + 4 * h) : trash;
-        *reinterpret_cast<f32x4*>(pdst) = b;
-      }
-  } else {
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = live && feat_lt(t, r, 4 * h, d);
-        float* pdst = ok ? dst + base + feat(t, r, h) : trash;
-        *pdst = v[t][r];
-      }
-  }
-}
-
-// four consecutive features of one row (injected noise: parity mode only), tile t, quad q
-SD_INLINE f32x4 load_quad(const float* __restrict__ src, uint32_t row, int d, bool live, int t, int q, int h) {
-  const size_t base = static_cast<size_t>(row) * d;
+// ----------------------------------------------------------------------------------------------
+SD_INLINE f32x4 load_quad(const float* __restrict__ src, uint32_t row, int d, bool live, int t, int g) {
+  const size_t base = static_cast<size_t>(row) * d + 16 * t + 4 * g;
   f32x4 z;
+  if ((d & 3) == 0) {
+    const bool ok = live && feat_lt(t, 0, 4 * g, d);
+    z = *reinterpret_cast<const f32x4*>(src + (ok ? base : 0));
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const bool ok = live && feat_lt(t, 4 * q + e, 4 * h, d);
-    const float b = src[ok ? base + (32 * t + 8 * q + 4 * h + e) : 0];
-    z[e] = ok ? b : 0.0f;
+    for (int r = 0; r < 4; ++r) z[r] = ok ? z[r] : 0.0f;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = live && feat_lt(t, r, 4 * g, d);
+      const float b = src[ok ? base + r : 0];
+      z[r] = ok ? b : 0.0f;
+    }
   }
   return z;
+}
+
+SD_INLINE void store_quad(float* __restrict__ dst, float* __restrict__ trash, uint32_t row, int d, bool live, int t, int g, f32x4 v) {
+  const size_t base = static_cast<size_t>(row) * d + 16 * t + 4 * g;
+  if ((d & 3) == 0) {
+    const bool ok = live && feat_lt(t, 0, 4 * g, d);
+    *reinterpret_cast<f32x4*>(ok ? dst + base : trash) = v;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = live && feat_lt(t, r, 4 * g, d);
+      *(ok ? dst + base + r : trash) = v[r];
+    }
+  }
+}
+
+template <int NT>
+SD_INLINE void load_rows(const float* __restrict__ src, uint32_t row, int d, bool live, int g, f32x4 (&v)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) v[t] = load_quad(src, row, d, live, t, g);
+}
+template <int NT>
+SD_INLINE void store_rows(float* __restrict__ dst, float* __restrict__ trash, uint32_t row, int d, bool live, int g,
+                          const f32x4 (&v)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) store_quad(dst, trash, row, d, live, t, g, v[t]);
 }
 
 // ----------------------------------------------------------------------------------------------
 // CMCD building blocks (eq/sdes.py:101-110, distr/logistic_regression.py, distr/gauss.py:129-135)
 // ----------------------------------------------------------------------------------------------
-#define SD_LR_ROWS 192      // data rows padded to 6 tiles of 32 (sonar: 166)
-#define SD_LR_STRIDE 65     // LDS row stride of the design-matrix image (odd: conflict-free in both products)
+#define SD_LR_ROWS 192      // data rows padded to 12 tiles of 16 (sonar: 166)
+#define SD_LR_STRIDE 65     // LDS row stride of the design-matrix image (odd: at most 2-way conflicts both ways)
 
 // Dense product whose A operands come from ONE plain LDS image M[rows][SD_LR_STRIDE] (ds_read_b32 per k-step):
-//   TRANS = 0: out[to] += M[32 to + i][feat(ti, r, h)]      (rows = outputs)      logits = X w
-//   TRANS = 1: out[to] += M[feat(ti, r, h)][32 to + i]      (rows = summation)    grad   = X^T r
-// Both address patterns are bank-conflict-free with the odd stride, so the design matrix is stored once.
+//   TRANS = 0: out[to] += M[16 (to+out0) + i][feat(ti+in0, r, g)]      (rows = outputs)      logits = X w
+//   TRANS = 1: out[to] += M[feat(ti+in0, r, g)][16 (to+out0) + i]      (rows = summation)    grad   = X^T r
+// so the design matrix is stored once and read in both orientations.
 template <int TI, int TO, int TRANS>
-SD_INLINE void dense_plain(const f32x16 (&in)[TI], f32x16 (&out)[TO], const float* m, int lane, int in_tile0, int out_tile0) {
-  const int i = lane & 31, h = lane >> 5;
+SD_INLINE void dense_plain(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* m, int lane, int in0, int out0) {
+  const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int to = 0; to < TO; ++to)
+  for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kf = 32 * (ti + in_tile0) + 8 * (r >> 2) + (r & 3);  // + 4h below
-        const int o = 32 * (to + out_tile0) + i;
-        const float a = TRANS ? m[(kf + 4 * h) * SD_LR_STRIDE + o] : m[o * SD_LR_STRIDE + kf + 4 * h];
-        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[ti][r], out[to], 0, 0, 0);
+      for (int to = 0; to < TO; ++to) {
+        const int kf = 16 * (ti + in0) + 4 * g + r;
+        const int o = 16 * (to + out0) + i;
+        const float a = TRANS ? m[kf * SD_LR_STRIDE + o] : m[o * SD_LR_STRIDE + kf];
+        out[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, in[ti][r], out[to], 0, 0, 0);
       }
 }
 

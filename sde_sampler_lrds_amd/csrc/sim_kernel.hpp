@@ -1,19 +1,19 @@
 // The persistent whole-trajectory simulate kernel (FORM_LIN / FORM_EM) for gfx950.
 //
-// One launch runs all N steps.  A wave keeps its 32 particles' state x[d] in registers for the whole
+// One launch runs all N steps.  A wave keeps its 16 particles' state x[d] in registers for the whole
 // trajectory; HBM sees x once in and once out ((2d+1)*4 bytes per particle per TRAJECTORY).  Per step a
 // wave does: drift net (FP32 MFMA chain, weights in LDS), optional target score inside the control
-// (ScoreCtrl/LerpCtrl), optional reference score (noised Gaussian / mixture, tables per step from L2),
-// noise (Philox in-register or injected), the integrator update and the log-RND accumulation
-// (one cross-half shuffle per reduction).  No barrier inside the step loop: the two waves sharing a SIMD
-// drift apart so that one's MFMA phase overlaps the other's VALU phase.
+// (ScoreCtrl/LerpCtrl), optional reference score (noised Gaussian / mixture; per-wave LDS table refilled by
+// LDS-DMA), noise (Philox in-register or injected), the integrator update and the log-RND accumulation
+// (two cross-lane adds per reduction).  No barrier inside the step loop: the four waves sharing a SIMD drift
+// apart so that one's MFMA phase overlaps the others' vector phases and memory waits.
 #pragma once
 #include "sim_device.hpp"
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };  // GMM: K <= SD_KREG (responsibilities in registers)
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
 
-// score part of the generative control for one feature tile (added to clip(net)):
+// score part of the generative control (added to clip(net)):
 //   ScoreCtrl (models/reparam.py:112-117):  scale*clip(score_pi(x)) * s_theta(t)
 //   LerpCtrl  (models/reparam.py:166-199):  g(t) * (scale*clip(lerp(score_prior, score_pi, t/T)) * s_theta(t))
 SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, float score_gain, float lerp_w,
@@ -31,146 +31,127 @@ SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, 
   return v;
 }
 
-// PAR = 1 adds the parity-mode paths (injected noise, trajectory dump); PAR = 0 keeps them out of the step loop,
-// whose code must stay inside the 64 KB instruction cache two CUs share.
-template <int DT, int REF, int SC, int FORM, int PAR>
+// PAR = 1 adds the parity-mode paths (injected noise, trajectory dump); PAR = 0 keeps them out of the step loop.
+template <int NT, int REF, int SC, int FORM, int PAR>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const SimArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int dpad = 32 * DT;
+  constexpr int dpad = 16 * NT;
+  constexpr int OT = NT >= 2 ? 2 : 1;  // output tiles produced together: two independent MFMA chains
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {  // packed drift-net weights -> LDS, once per workgroup
     const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    const int n4 = sd_lds_weight_floats(DT) / 4;
+    const int n4 = sd_lds_weight_floats(NT) / 4;
     for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
   }
   __syncthreads();
-  const float* bias = a.wpack + sd_off_bias(DT);
+  const float* bias = a.wpack + sd_off_bias(NT);
   // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)
   constexpr bool ref_lds = (REF == RF_GAUSS || REF == RF_GMM);
-  float* my_tab = lds + sd_lds_weight_floats(DT) + wave * SD_REFTAB_FLOATS;
+  float* my_tab = lds + sd_lds_weight_floats(NT) + wave * SD_REFTAB_FLOATS;
   const int tab_floats = a.ref_k * 2 * dpad;
-  // Stagger: the two waves that share a SIMD run the same program and would stay in lockstep (both in their
-  // MFMA phase, then both in their VALU phase, sharing each pipe in turn).  Delaying the second-dispatched half
-  // by about half a step puts one wave's matrix phase beside its partner's vector phase for the whole
-  // trajectory (MI355X_MICROARCH.md, 'Two waves per SIMD', item 9).  Results do not depend on it.
-  if (wave >= SD_WAVES / 2) {
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  const int p = lane & 31, h = lane >> 5;
+  const int p = lane & 15, g = lane >> 4;
   constexpr bool lin = FORM == SDENG_FORM_LIN;
   const bool full_d = a.d == dpad;
   float* trash = a.trash + tid * 4;
 
   for (int tile = blockIdx.x * SD_WAVES + wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {
-    const uint32_t row = static_cast<uint32_t>(tile) * 32u + p;
+    const uint32_t row = static_cast<uint32_t>(tile) * 16u + p;
     const bool live = row < static_cast<uint32_t>(a.B);
     const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
-    f32x16 x[DT];
-    load_rows<DT>(a.x_in, row, a.d, live, h, x);
+    f32x4 x[NT];
+    load_rows<NT>(a.x_in, row, a.d, live, g, x);
     // rnd0 = log p_prior(x0) when the loss asks for it (losses/oc.py:695-699, 935-939), from k_dist_eval
     float rnd = 0.0f;
     if (a.rnd_init) rnd = (live ? a.rnd_init[row] : 0.0f);
     if constexpr (PAR) {
-      if (a.xs_out) store_rows<DT>(a.xs_out, trash, row, a.d, live, h, x);
+      if (a.xs_out) store_rows<NT>(a.xs_out, trash, row, a.d, live, g, x);
     }
-
     if constexpr (ref_lds) {
       if (a.N > 0) dma_table_to_lds(a.ref_tab, my_tab, tab_floats, lane);
     }
+
     for (int k = 0; k < a.N; ++k) {
       const float* cf = a.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5], c6 = cf[6];
       const float score_gain = cf[7], lerp_w = cf[8];
-      // `d` re-read through an opaque move every step: keeps the per-element pad masks (f < d) from being
-      // hoisted out of the step loop, where 64 of them would occupy 128 SGPRs and spill
+      // `d` re-read through an opaque move every step: keeps the pad masks (f < d) from being hoisted out of
+      // the step loop, where they would occupy SGPR pairs and spill
       int d_dyn = a.d;
       asm volatile("" : "+s"(d_dyn));
 
       // ---- drift net up to the last hidden activation (FP32 MFMA chain) ----
-      f32x16 hid[2];
-      mlp_hidden<DT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
+      f32x4 hid[SD_HT];
+      mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
-      f32x16 ts[SC != SC_NONE ? DT : 1];
-      if constexpr (SC == SC_GMM) gmm_score<DT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, h, ts);
-      if constexpr (SC == SC_PHI4) phi4_score<DT>(x, a.target, d_dyn, h, ts);
+      f32x4 ts[SC != SC_NONE ? NT : 1];
+      if constexpr (SC == SC_GMM) gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
+      if constexpr (SC == SC_PHI4) phi4_score<NT>(x, a.target, d_dyn, g, lane, ts);
       // reference drift (eq/sdes.py:265-279, 329-345): small mixtures keep only the K responsibilities and
-      // assemble the score quad by quad in the tail; larger ones use the online-softmax accumulator
+      // assemble the score tile by tile in the tail; larger ones use the online-softmax accumulator
       const float* rtab = ref_lds ? my_tab : a.ref_tab + static_cast<size_t>(k) * tab_floats;
       const float* rcs = a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2;
       if constexpr (ref_lds) wait_dma();
       float resp[REF == RF_GMM ? SD_KREG : 1];
-      f32x16 rs[REF == RF_GMM_BIG ? DT : 1];
-      if constexpr (REF == RF_GMM) gmm_resp<DT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, h, resp);
-      if constexpr (REF == RF_GMM_BIG) gmm_score<DT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, h, rs);
+      f32x4 rs[REF == RF_GMM_BIG ? NT : 1];
+      if constexpr (REF == RF_GMM) gmm_resp<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, resp);
+      if constexpr (REF == RF_GMM_BIG) gmm_score<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, rs);
       __builtin_amdgcn_sched_barrier(0);
       float st = 1.0f;
       if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[k] : 1.0f;
 
-      // ---- per output tile: out_layer (MFMA) -> clip -> cost -> noise -> integrator -> Ito term ----
+      // ---- per pair of output tiles: out_layer (MFMA) -> clip -> cost -> noise -> integrator -> Ito term ----
       float su2 = 0.0f, suz = 0.0f;
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        // keep the tiles in program order: one 16-register output tile live at a time (the scheduler otherwise
-        // hoists all DT tiles' MFMAs ahead of the vector work and spills)
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 u = mlp_out_tile<DT>(hid, lds, bias, t, lane);
+      for (int t0 = 0; t0 < NT; t0 += OT) {
+        f32x4 u[OT];
+        mlp_out_tiles<NT, OT>(hid, lds, bias, t0, lane, u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float uv = u[r];
-          if (a.clip_model > 0.0f) uv = clampf(uv, a.clip_model);
-          if constexpr (SC != SC_NONE)
-            uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * h, d_dyn));
-          u[r] = uv;
-          su2 = __builtin_fmaf(uv, uv, su2);
-        }
+        for (int o = 0; o < OT; ++o) {
+          const int t = t0 + o;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int fb = 32 * t + 8 * q + 4 * h;
+          for (int r = 0; r < 4; ++r) {
+            float uv = u[o][r];
+            if (a.clip_model > 0.0f) uv = clampf(uv, a.clip_model);
+            if constexpr (SC != SC_NONE)
+              uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * g, d_dyn));
+            u[o][r] = uv;
+            su2 = __builtin_fmaf(uv, uv, su2);
+          }
           f32x4 z;
           if (PAR && a.noise_in) {
-            z = load_quad(a.noise_in + static_cast<size_t>(k) * a.B * a.d, row, d_dyn, live, t, q, h);
+            z = load_quad(a.noise_in + static_cast<size_t>(k) * a.B * a.d, row, d_dyn, live, t, g);
           } else {
-            z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(fb >> 2), 0u, a.seed_lo, a.seed_hi);
+            z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, a.seed_lo, a.seed_hi);
             // pad features (f >= d) may carry noise: their weights, table entries and outputs are all zero, so
             // they never reach a live feature -- except through the phi^4 lattice's neighbour coupling
             if constexpr (SC == SC_PHI4) {
               if (!full_d) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) z[e] = feat_lt(t, 4 * q + e, 4 * h, d_dyn) ? z[e] : 0.0f;
+                for (int r = 0; r < 4; ++r) z[r] = feat_lt(t, r, 4 * g, d_dyn) ? z[r] : 0.0f;
               }
             }
           }
-          f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};  // reference score of this quad
-          if constexpr (REF == RF_GMM) rq = gmm_score_quad<DT>(x, rtab, a.ref_k, h, resp, t, q);
-          if constexpr (REF == RF_GMM_BIG) {
+          f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};  // reference score of this tile
+          if constexpr (REF == RF_GMM) rq = gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
+          if constexpr (REF == RF_GMM_BIG) rq = rs[t];
+          if constexpr (REF == RF_GAUSS) rq = gauss_score_tile<NT>(x, rtab, g, t);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rq[e] = rs[t][4 * q + e];
-          }
-          if constexpr (REF == RF_GAUSS) {
-            const float* mp = rtab + 4 * h + 32 * t + 8 * q;
-            const f32x4 m = *reinterpret_cast<const f32x4*>(mp);
-            const f32x4 iv = *reinterpret_cast<const f32x4*>(mp + dpad);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rq[e] = -((x[t][4 * q + e] - m[e]) * iv[e]);  // distr/gauss.py:124-126
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * q + e;
-            const float xv = x[t][r], uv = u[r];
+          for (int r = 0; r < 4; ++r) {
+            const float xv = x[t][r], uv = u[o][r];
             if constexpr (lin) {  // eq/sdes.py:535-538: ret = c1*x + c2*(ref + u); ret += c3*z
               float sc = uv;
-              if constexpr (REF != RF_NONE) sc = rq[e] + uv;
-              x[t][r] = (c1 * xv + c2 * sc) + c3 * z[e];
-              suz = __builtin_fmaf(uv, z[e], suz);
+              if constexpr (REF != RF_NONE) sc = rq[r] + uv;
+              x[t][r] = (c1 * xv + c2 * sc) + c3 * z[r];
+              suz = __builtin_fmaf(uv, z[r], suz);
             } else {  // losses/oc.py:277-284
-              const float db = z[e] * c5;
+              const float db = z[r] * c5;
               float f = c1 * xv;
-              if constexpr (REF != RF_NONE) f = f + c3 * rq[e];
+              if constexpr (REF != RF_NONE) f = f + c3 * rq[r];
               x[t][r] = xv + (f + c2 * uv) * c4 + c2 * db;
               suz = __builtin_fmaf(uv, db, suz);
             }
@@ -183,28 +164,28 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       }
       // running cost 0.5*omega*|u|^2 (losses/oc.py:493) or 0.5*|u|^2*dt (:274); per-step constant
       // (TimeReversalLoss: -int drift divergence, :1218-1219); stochastic integral (:284, :499)
-      su2 = half_sum(su2);
+      su2 = group_sum(su2);
       rnd += lin ? c4 * su2 : (0.5f * su2) * c4;
       rnd += c6;
       if (a.flags & SDENG_FLAG_ITO) {
-        suz = half_sum(suz);
+        suz = group_sum(suz);
         rnd += lin ? c5 * suz : suz;
       }
       if constexpr (PAR) {
-        if (a.xs_out) store_rows<DT>(a.xs_out + static_cast<size_t>(k + 1) * a.B * a.d, trash, row, d_dyn, live, h, x);
+        if (a.xs_out) store_rows<NT>(a.xs_out + static_cast<size_t>(k + 1) * a.B * a.d, trash, row, d_dyn, live, g, x);
       }
     }
 
     // the terminal cost (losses/oc.py:290, :973) is added by k_terminal from x_out: it runs once per
     // trajectory, and keeping every distribution's log-density out of this kernel keeps its registers free
-    store_rows<DT>(a.x_out, trash, row, a.d, live, h, x);
-    if (live && h == 0) a.rnd_out[row] = rnd;
+    store_rows<NT>(a.x_out, trash, row, a.d, live, g, x);
+    if (live && g == 0) a.rnd_out[row] = rnd;
   }
 }
 
 // Generative control alone, u(t, x) for a whole batch at one time (unit parity tests of the drift net and
 // the ctrl wrappers against the oracle; same device code as the step loop, k = 0 of one-row tables).
-template <int DT, int SC>
+template <int NT, int SC>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const SimArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -213,74 +194,70 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    const int n4 = sd_lds_weight_floats(DT) / 4;
+    const int n4 = sd_lds_weight_floats(NT) / 4;
     for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
   }
   __syncthreads();
-  const float* bias = a.wpack + sd_off_bias(DT);
-  const int p = lane & 31, h = lane >> 5;
+  const float* bias = a.wpack + sd_off_bias(NT);
+  const int p = lane & 15, g = lane >> 4;
   float* trash = a.trash + tid * 4;
   for (int tile = blockIdx.x * SD_WAVES + wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {
-    const uint32_t row = static_cast<uint32_t>(tile) * 32u + p;
+    const uint32_t row = static_cast<uint32_t>(tile) * 16u + p;
     const bool live = row < static_cast<uint32_t>(a.B);
-    f32x16 x[DT];
-    load_rows<DT>(a.x_in, row, a.d, live, h, x);
+    f32x4 x[NT];
+    load_rows<NT>(a.x_in, row, a.d, live, g, x);
     const float score_gain = a.coef[7], lerp_w = a.coef[8];
-    f32x16 hid[2];
-    mlp_hidden<DT>(x, hid, lds, bias, a.temb, lane);
-    f32x16 ts[SC != SC_NONE ? DT : 1];
-    if constexpr (SC == SC_GMM) gmm_score<DT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, h, ts);
-    if constexpr (SC == SC_PHI4) phi4_score<DT>(x, a.target, a.d, h, ts);
+    f32x4 hid[SD_HT];
+    mlp_hidden<NT>(x, hid, lds, bias, a.temb, lane);
+    f32x4 ts[SC != SC_NONE ? NT : 1];
+    if constexpr (SC == SC_GMM) gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
+    if constexpr (SC == SC_PHI4) phi4_score<NT>(x, a.target, a.d, g, lane, ts);
     float st = 1.0f;
     if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[0] : 1.0f;
-    f32x16 u[DT];
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
-      u[t] = mlp_out_tile<DT>(hid, lds, bias, t, lane);
+    for (int t = 0; t < NT; ++t) {
+      f32x4 u[1];
+      mlp_out_tiles<NT, 1>(hid, lds, bias, t, lane, u);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float uv = u[t][r];
+      for (int r = 0; r < 4; ++r) {
+        float uv = u[0][r];
         if (a.clip_model > 0.0f) uv = clampf(uv, a.clip_model);
         if constexpr (SC != SC_NONE)
-          uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * h, a.d));
-        u[t][r] = uv;
+          uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * g, a.d));
+        u[0][r] = uv;
       }
+      store_quad(a.x_out, trash, row, a.d, live, t, g, u[0]);
     }
-    store_rows<DT>(a.x_out, trash, row, a.d, live, h, u);
   }
 }
 
-template <int DT, int SC>
+template <int NT, int SC>
 static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(DT, false));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_forward<DT, SC>),
+  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, false));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctrl_forward<NT, SC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_ctrl_forward<DT, SC>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_ctrl_forward<NT, SC>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
 }
-#define SD_DEFINE_CTRL(DT, SC) \
-  int sd_launch_ctrl_##DT##_##SC(const SimArgs& a, int grid, hipStream_t s) { return launch_ctrl_forward<DT, SC>(a, grid, s); }
-#define SD_DECLARE_CTRL(DT, SC) int sd_launch_ctrl_##DT##_##SC(const SimArgs& a, int grid, hipStream_t s);
+#define SD_DEFINE_CTRL(NT, SC) \
+  int sd_launch_ctrl_##NT##_##SC(const SimArgs& a, int grid, hipStream_t s) { return launch_ctrl_forward<NT, SC>(a, grid, s); }
 
-// host-side launcher, one per instantiation (defined in sim_inst_*.hip)
-typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
-
-template <int DT, int REF, int SC, int FORM, int PAR>
+// host-side launcher, one per instantiation (defined in gen/sim_*.hip)
+template <int NT, int REF, int SC, int FORM, int PAR>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(DT, REF == RF_GAUSS || REF == RF_GMM));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<DT, REF, SC, FORM, PAR>),
+  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_simulate<DT, REF, SC, FORM, PAR>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_simulate<NT, REF, SC, FORM, PAR>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
 }
-template <int DT, int REF, int SC, int FORM>
+template <int NT, int REF, int SC, int FORM>
 static int launch_simulate(const SimArgs& a, int grid, hipStream_t stream) {
-  if (a.noise_in || a.xs_out) return launch_simulate_par<DT, REF, SC, FORM, 1>(a, grid, stream);
-  return launch_simulate_par<DT, REF, SC, FORM, 0>(a, grid, stream);
+  if (a.noise_in || a.xs_out) return launch_simulate_par<NT, REF, SC, FORM, 1>(a, grid, stream);
+  return launch_simulate_par<NT, REF, SC, FORM, 0>(a, grid, stream);
 }
 
-#define SD_DEFINE_SIM(DT, REF, SC, FORM) \
-  int sd_launch_sim_##DT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s) { return launch_simulate<DT, REF, SC, FORM>(a, grid, s); }
-#define SD_DECLARE_SIM(DT, REF, SC, FORM) int sd_launch_sim_##DT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s);
+#define SD_DEFINE_SIM(NT, REF, SC, FORM) \
+  int sd_launch_sim_##NT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s) { return launch_simulate<NT, REF, SC, FORM>(a, grid, s); }
