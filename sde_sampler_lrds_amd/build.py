@@ -24,6 +24,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the integrator and log-weight updates must round like the reference's separate
 # torch ops (no silent a*b+c fusion); fused multiply-adds are written explicitly where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wno-comment"]
+if os.environ.get("SDENG_DEFS"):  # experiment knob: extra -D flags (ablation builds)
+    FLAGS += ["-D" + d for d in os.environ["SDENG_DEFS"].split()]
 if os.environ.get("SDENG_WAVES"):  # experiment knob: waves per workgroup (8 = 2 per SIMD, 4 = 1 per SIMD)
     FLAGS.append("-DSD_WAVES=" + os.environ["SDENG_WAVES"])
 

@@ -81,12 +81,49 @@ SD_INLINE void dense(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* w, in
   }
 }
 
+// two GELUs at once: the polynomial pieces run as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth
+// of work per issue slot); exp, abs/copysign and the selects stay scalar.  Same arithmetic as gelu().
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+SD_INLINE f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+SD_INLINE f32x2 splat2(float v) { return f32x2{v, v}; }
+SD_INLINE f32x2 gelu2(f32x2 v) {
+#ifdef SD_DBG_NOGELU
+  return v * splat2(0.5f);
+#endif
+  const f32x2 a = v * splat2(0.70710678118654752440f);
+  const f32x2 t = __builtin_elementwise_abs(a);
+  const f32x2 s = a * a;
+  f32x2 r = pk_fma(splat2(-1.72853470e-5f), t, splat2(3.83197126e-4f));
+  const f32x2 u = pk_fma(splat2(-3.88396438e-3f), t, splat2(2.42546219e-2f));
+  r = pk_fma(r, s, u);
+  r = pk_fma(r, t, splat2(-1.06777877e-1f));
+  r = pk_fma(r, t, splat2(-6.34846687e-1f));
+  r = pk_fma(r, t, splat2(-1.28717512e-1f));
+  r = pk_fma(r, t, -t);
+  r = r * splat2(1.4426950408889634f);
+  f32x2 big;
+  big.x = __builtin_copysignf(1.0f - __builtin_amdgcn_exp2f(r.x), a.x);
+  big.y = __builtin_copysignf(1.0f - __builtin_amdgcn_exp2f(r.y), a.y);
+  f32x2 q = pk_fma(splat2(-5.96761703e-4f), s, splat2(4.99119423e-3f));
+  q = pk_fma(q, s, splat2(-2.67681349e-2f));
+  q = pk_fma(q, s, splat2(1.12819925e-1f));
+  q = pk_fma(q, s, splat2(-3.76125336e-1f));
+  q = pk_fma(q, s, splat2(1.28379166e-1f));
+  const f32x2 small = pk_fma(q, a, a);
+  f32x2 e;
+  e.x = (t.x > 0.927734375f) ? big.x : small.x;
+  e.y = (t.y > 0.927734375f) ? big.y : small.y;
+  return (v * splat2(0.5f)) * (splat2(1.0f) + e);
+}
+
 template <int T>
 SD_INLINE void gelu_tiles(f32x4 (&v)[T]) {
 #pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[t][r] = gelu(v[t][r]);
+  for (int t = 0; t < T; ++t) {
+    const f32x2 lo = gelu2(f32x2{v[t][0], v[t][1]});
+    const f32x2 hi = gelu2(f32x2{v[t][2], v[t][3]});
+    v[t] = f32x4{lo.x, lo.y, hi.x, hi.y};
+  }
 }
 
 // FourierMLP.forward (models/mlp.py:135-143) for a 16-particle tile, split in two so that the d-wide output
@@ -144,8 +181,12 @@ SD_INLINE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                              uint32_t (&o)[4]) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of a mul_hi/mul_lo pair: integer multiplies
+    // are quarter-rate and were the single largest vector cost of the step
+    const uint64_t p0 = static_cast<uint64_t>(0xD2511F53u) * c0;
+    const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
+    const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
+    const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0;
     c1 = lo1;
@@ -168,7 +209,11 @@ SD_INLINE float u01(uint32_t bits) { return (static_cast<float>(bits >> 9) + 0.5
 // partial round can be hoisted out of the step loop.
 SD_INLINE f32x4 philox_normal4(uint32_t pidx, uint32_t step, uint32_t jb, uint32_t stream, uint32_t k0, uint32_t k1) {
   uint32_t r[4];
+#ifdef SD_DBG_NOPHILOX
+  r[0] = pidx * 2654435761u + step; r[1] = jb * 40503u + step; r[2] = r[0] ^ 0x9E3779B9u; r[3] = r[1] + k0;
+#else
   philox4x32_10(pidx, jb, step, stream, k0, k1, r);
+#endif
   f32x4 z;
   // rad = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u); v_sin/v_cos take revolutions: sin(2 pi u) directly
   const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r[0])));
