@@ -65,7 +65,7 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
       df[t] = x[t] - load_tile4(a.prior_loc, t, g);
       ps[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    dense<NT, NT>(df, ps, xim + SD_LR_ROWS * SD_LR_STRIDE, lane);
+    dense_f32<NT, NT>(df, ps, xim + SD_LR_ROWS * SD_LR_STRIDE, lane);
 #pragma unroll
     for (int t = 0; t < NT; ++t) ps[t] = -ps[t];
   } else {  // IsotropicGauss.score  distr/gauss.py:764-766

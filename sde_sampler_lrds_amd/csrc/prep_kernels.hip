@@ -13,38 +13,47 @@
 // ------------------------------------------------------------------------------------------------
 // weights -> packed LDS image.  One thread per packed float.
 // ------------------------------------------------------------------------------------------------
+// One thread per 16-bit half of the image.  Block (to, kb), part (0 = hi, 1 = lo), lane, j:
+//   w = W[16 to + (lane & 15)][16 (2 kb + j/4) + 4 (lane >> 4) + j%4];  hi = f16(w);  lo = f16((w - hi) * 2^11)
 __global__ void k_pack_mlp(PackArgs a) {
   const int NT = a.NT;
-  const int total = sd_pack_floats(NT);
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    float v;
-    if (idx < sd_off_bias(NT)) {
+  const int n_half = sd_lds_weight_floats(NT) * 2;
+  const int n_bias = 3 * 64 + 16 * NT;
+  _Float16* img = reinterpret_cast<_Float16*>(a.out);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_half + n_bias; idx += gridDim.x * blockDim.x) {
+    if (idx < n_half) {
+      const int fl = idx >> 1;  // float-equivalent offset, to find the layer
       const float* W;
-      int n_out, n_in, TI, local;
-      if (idx < sd_off_wh1(NT)) {
-        W = a.w_in; n_out = SD_H; n_in = a.d; TI = NT; local = idx - sd_off_win(NT);
-      } else if (idx < sd_off_wh2(NT)) {
-        W = a.w_h1; n_out = SD_H; n_in = SD_H; TI = SD_HT; local = idx - sd_off_wh1(NT);
-      } else if (idx < sd_off_wout(NT)) {
-        W = a.w_h2; n_out = SD_H; n_in = SD_H; TI = SD_HT; local = idx - sd_off_wh2(NT);
+      int n_out, n_in, KB, base;
+      if (fl < sd_off_wh1(NT)) {
+        W = a.w_in; n_out = SD_H; n_in = a.d; KB = sd_kb(NT); base = sd_off_win(NT);
+      } else if (fl < sd_off_wh2(NT)) {
+        W = a.w_h1; n_out = SD_H; n_in = SD_H; KB = 2; base = sd_off_wh1(NT);
+      } else if (fl < sd_off_wout(NT)) {
+        W = a.w_h2; n_out = SD_H; n_in = SD_H; KB = 2; base = sd_off_wh2(NT);
       } else {
-        W = a.w_out; n_out = a.d; n_in = SD_H; TI = SD_HT; local = idx - sd_off_wout(NT);
+        W = a.w_out; n_out = a.d; n_in = SD_H; KB = 2; base = sd_off_wout(NT);
       }
-      // local = ((to*TI + ti)*64 + lane)*4 + r  ->  W[16 to + (lane & 15)][feat(ti, r, lane >> 4)]
-      const int r = local & 3;
-      const int lane = (local >> 2) & 63;
-      const int pair = local >> 8;
-      const int ti = pair % TI, to = pair / TI;
-      const int o = 16 * to + (lane & 15), i = feat(ti, r, lane >> 4);
-      v = (o < n_out && i < n_in) ? W[static_cast<size_t>(o) * n_in + i] : 0.0f;
+      const int local = idx - 2 * base;          // half index inside the layer
+      const int j = local & 7;
+      const int lane = (local >> 3) & 63;
+      const int part = (local >> 9) & 1;
+      const int blk = local >> 10;
+      const int kb = blk % KB, to = blk / KB;
+      const int o = 16 * to + (lane & 15);
+      const int i = 16 * (2 * kb + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+      const float w = (o < n_out && i < n_in) ? W[static_cast<size_t>(o) * n_in + i] : 0.0f;
+      const _Float16 hi = static_cast<_Float16>(w);
+      img[idx] = part == 0 ? hi : static_cast<_Float16>((w - static_cast<float>(hi)) * 2048.0f);
     } else {
-      const int b = idx - sd_off_bias(NT);
+      const int b = idx - n_half;
+      float v;
       if (b < 64) v = a.b_in[b];
       else if (b < 128) v = a.b_h1[b - 64];
       else if (b < 192) v = a.b_h2[b - 128];
       else v = (b - 192 < a.d) ? a.b_out[b - 192] : 0.0f;
+      a.out[sd_off_bias(NT) + b] = v;
     }
-    a.out[idx] = v;
   }
 }
 
@@ -482,7 +491,7 @@ __global__ void k_philox(unsigned seed_lo, unsigned seed_hi, int step, long long
 
 // ---- host-side launch wrappers -------------------------------------------------------------------
 int sd_launch_pack(const PackArgs& a, hipStream_t s) {
-  const int total = sd_pack_floats(a.NT);
+  const int total = sd_lds_weight_floats(a.NT) * 2 + 3 * 64 + 16 * a.NT;
   hipLaunchKernelGGL(k_pack_mlp, dim3((total + 255) / 256), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }

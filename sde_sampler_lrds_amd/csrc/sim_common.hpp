@@ -32,13 +32,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define SD_THREADS (SD_WAVES * 64)
 
-// packed drift-net image (floats): one (out-tile, in-tile) pair = 16x16 weights = 256 floats
-//   W_in [4][NT] pairs, W_h1 [4][4], W_h2 [4][4], W_out [NT][4]; then b_in, b_h1, b_h2 (64 each), b_out (16*NT)
+// Packed drift-net image.  The GEMMs run on the f16 matrix pipe as a two-piece split (see sim_device.hpp,
+// dense_f16x2): every weight is stored as hi = f16(w) and lo = f16((w - hi) * 2^11).  One block = one
+// (16-output tile, 32-input K-block) = 64 lanes x 8 halves for hi, then the same for lo = 2 KiB = 512 floats.
+//   W_in [4][KB(NT)] blocks, W_h1 [4][2], W_h2 [4][2], W_out [NT][2]; then b_in, b_h1, b_h2 (64 each), b_out (16*NT)
+__host__ __device__ inline int sd_kb(int NT) { return (NT + 1) / 2; }  // 32-feature K-blocks covering NT tiles
 __host__ __device__ inline int sd_off_win(int NT) { return 0; }
-__host__ __device__ inline int sd_off_wh1(int NT) { return 4 * NT * 256; }
-__host__ __device__ inline int sd_off_wh2(int NT) { return (4 * NT + 16) * 256; }
-__host__ __device__ inline int sd_off_wout(int NT) { return (4 * NT + 32) * 256; }
-__host__ __device__ inline int sd_lds_weight_floats(int NT) { return (8 * NT + 32) * 256; }
+__host__ __device__ inline int sd_off_wh1(int NT) { return 4 * sd_kb(NT) * 512; }
+__host__ __device__ inline int sd_off_wh2(int NT) { return sd_off_wh1(NT) + 4 * 2 * 512; }
+__host__ __device__ inline int sd_off_wout(int NT) { return sd_off_wh2(NT) + 4 * 2 * 512; }
+__host__ __device__ inline int sd_lds_weight_floats(int NT) { return sd_off_wout(NT) + NT * 2 * 512; }
 __host__ __device__ inline int sd_off_bias(int NT) { return sd_lds_weight_floats(NT); }
 __host__ __device__ inline int sd_pack_floats(int NT) { return sd_lds_weight_floats(NT) + 3 * 64 + 16 * NT; }
 // per-wave LDS copy of one step's reference table [K][2][dpad]; used while K*2*dpad <= SD_REFTAB_FLOATS

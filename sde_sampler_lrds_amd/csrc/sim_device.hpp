@@ -67,7 +67,7 @@ SD_INLINE f32x4 load_tile4(const float* base, int t, int g) { return *reinterpre
 // go to different accumulators (dependent latency 40 cycles vs 32-cycle issue).
 // ----------------------------------------------------------------------------------------------
 template <int TI, int TO>
-SD_INLINE void dense(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* w, int lane) {
+SD_INLINE void dense_f32(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* w, int lane) {
   const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti) {
@@ -79,6 +79,68 @@ SD_INLINE void dense(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* w, in
 #pragma unroll
       for (int to = 0; to < TO; ++to) out[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to][r], in[ti][r], out[to], 0, 0, 0);
   }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Split-f16 dense layer on the f16 matrix pipe (v_mfma_f32_16x16x32_f16, fp32 accumulate).
+//
+// Why: on gfx950 an MFMA and vector instructions of the waves sharing a SIMD do not overlap (microbenchmark
+// tools/ubench/pipe_share.hip, profiles/r01_ubench_mfma_valu_serialize.log: times add), so the step costs
+// T_mfma + T_valu and the FP32 MFMA (64 FLOP/clk/SIMD) was 46 % of it.  Writing each operand as
+// v = hi + lo * 2^-11 with hi = f16(v), lo = f16((v - hi) * 2^11) (v - hi is exact in fp32) and summing the
+// three products hi*hi + 2^-11 (hi*lo + lo*hi) in fp32 reproduces the fp32 GEMM to fp32 round-off (22+ bits
+// per operand; measured rms error 1.00-1.06x that of an fp32 GEMM against fp64) at 3/16 of its matrix time.
+//
+// K-block kb covers feature tiles 2kb, 2kb+1: lane (p,g) contributes its 8 registers of those two tiles as the
+// 8 k-values of its group, k-slot (g, j) <-> feature 16 (2kb + j/4) + 4 g + j%4; the weights are stored in the
+// same permutation (k_pack_mlp).  `w` image: 16-byte vectors, index ((to*KB + kb)*2 + part)*64 + lane.
+// ----------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define SD_LO_SCALE 2048.0f
+#define SD_LO_INV 4.8828125e-04f
+
+SD_INLINE void split8(const f32x4& t0, const f32x4& t1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = j < 4 ? t0[j & 3] : t1[j & 3];
+    const _Float16 h = static_cast<_Float16>(v);
+    hi[j] = h;
+    lo[j] = static_cast<_Float16>((v - static_cast<float>(h)) * SD_LO_SCALE);
+  }
+}
+
+// one layer: out[to] = bias[to] (preloaded in `out`) + W in.  The activations are split K-block by K-block right
+// before use, so only 8 packed registers of hi/lo pieces are live at a time.
+template <int NTI, int TO>
+SD_INLINE void dense(const f32x4 (&in)[NTI], f32x4 (&out)[TO], const float* w, int lane) {
+  constexpr int KB = (NTI + 1) / 2;
+  const f16x8* w8 = reinterpret_cast<const f16x8*>(w);
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 mx[TO];
+#pragma unroll
+  for (int to = 0; to < TO; ++to) mx[to] = zero;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    f16x8 xh, xl;
+    split8(in[2 * kb], (2 * kb + 1 < NTI) ? in[2 * kb + 1 < NTI ? 2 * kb + 1 : 0] : zero, xh, xl);
+    f16x8 ah[TO], al[TO];
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+      ah[to] = w8[((to * KB + kb) * 2 + 0) * 64 + lane];
+      al[to] = w8[((to * KB + kb) * 2 + 1) * 64 + lane];
+    }
+    // acc_hh += Whi Xhi ; acc_mx += Whi Xlo + Wlo Xhi ; consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int to = 0; to < TO; ++to) out[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[to], xh, out[to], 0, 0, 0);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) mx[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[to], xl, mx[to], 0, 0, 0);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) mx[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[to], xh, mx[to], 0, 0, 0);
+  }
+#pragma unroll
+  for (int to = 0; to < TO; ++to)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[to][r] = __builtin_fmaf(mx[to][r], SD_LO_INV, out[to][r]);
 }
 
 // two GELUs at once: the polynomial pieces run as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth
@@ -157,7 +219,7 @@ SD_INLINE void mlp_out_tiles(const f32x4 (&a)[SD_HT], const float* lds, const fl
   const int g = lane >> 4;
 #pragma unroll
   for (int o = 0; o < OT; ++o) u[o] = load_tile4(bias + 192, t0 + o, g);  // b_out
-  dense<SD_HT, OT>(a, u, lds + sd_off_wout(NT) + t0 * SD_HT * 256, lane);
+  dense<SD_HT, OT>(a, u, lds + sd_off_wout(NT) + t0 * 2 * 512, lane);
 }
 
 // ----------------------------------------------------------------------------------------------
