@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
   float* trash = s.trash + tid * 4;
   const float gg = s.cmcd_g;
 
-  for (int tile = blockIdx.x * SD_WAVES + wave; tile < s.ntiles; tile += gridDim.x * SD_WAVES) {
+  for (int tile = blockIdx.x + gridDim.x * wave; tile < s.ntiles; tile += gridDim.x * SD_WAVES) {  // CUs first
     const uint32_t row = static_cast<uint32_t>(tile) * 16u + p;
     const bool live = row < static_cast<uint32_t>(s.B);
     const uint32_t pidx = static_cast<uint32_t>(s.particle0 + row);

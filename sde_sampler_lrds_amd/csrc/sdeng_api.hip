@@ -217,8 +217,9 @@ static int score_kind(const sdeng_desc* d, int& sc) {
 }
 
 static int grid_for(int ntiles) {
-  int g = (ntiles + SD_WAVES - 1) / SD_WAVES;
-  if (g > 256) g = 256;  // one persistent workgroup per CU (LDS image + 4 waves/SIMD fill a CU)
+  // one persistent workgroup per CU (LDS image + 2 waves/SIMD fill a CU); tiles are dealt to workgroups
+  // first, to the waves of a workgroup second, so a small batch spreads over the whole chip
+  int g = ntiles > 256 ? 256 : ntiles;
   return g < 1 ? 1 : g;
 }
 

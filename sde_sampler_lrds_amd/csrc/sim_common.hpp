@@ -15,10 +15,11 @@
 // no cross-lane traffic; the A operands (weights) are pre-permuted once into an LDS image by k_pack_mlp.
 //
 // Why 16-particle tiles (an earlier build used 32x32x2 MFMA, 32 particles per wave): the state of a tile is
-// half as many registers per lane (d=128: 32 instead of 64), so the kernel fits 4 waves per SIMD instead of 2.
-// PMC counters of the 32-wide build showed the matrix pipe 41 % busy with each wave spending 2.3x as long in
-// vector work and memory waits as in MFMA: two waves per SIMD cannot cover that, four can.  The FP32 MFMA
-// rate is the same for both shapes (64 FLOP/clk/SIMD).
+// half as many registers per lane (d=128: 32 instead of 64), so the whole step loop at d=128 fits the 256-VGPR
+// budget of 2 waves per SIMD with NO scratch traffic (235 VGPRs, 0 spills).  Measured on MI355X, cfg 2:
+// 4 waves/SIMD (128 VGPRs, spills) 10.2 ms, 2 waves/SIMD 7.6 ms, 1 wave/SIMD 9.6 ms.  On gfx950 MFMA and
+// VALU issue of the waves of one SIMD do not overlap (tools/ubench/pipe_share.hip), so extra occupancy buys
+// nothing once memory latency is covered; instruction count is what matters.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SD_H 64            // hidden channels (models/mlp.py: channels=64)
 #define SD_HT 4            // hidden channel tiles (64 / 16)
 #ifndef SD_WAVES
-#define SD_WAVES 16        // waves per workgroup (4 per SIMD)
+#define SD_WAVES 8         // waves per workgroup (2 per SIMD, 256-VGPR budget)
 #endif
 #define SD_THREADS (SD_WAVES * 64)
 

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   const bool full_d = a.d == dpad;
   float* trash = a.trash + tid * 4;
 
-  for (int tile = blockIdx.x * SD_WAVES + wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {
+  for (int tile = blockIdx.x + gridDim.x * wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {  // CUs first
     const uint32_t row = static_cast<uint32_t>(tile) * 16u + p;
     const bool live = row < static_cast<uint32_t>(a.B);
     const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
@@ -85,7 +85,6 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       // ---- drift net up to the last hidden activation (FP32 MFMA chain) ----
       f32x4 hid[SD_HT];
       mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
-      __builtin_amdgcn_sched_barrier(0);
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
       f32x4 ts[SC != SC_NONE ? NT : 1];
@@ -104,7 +103,6 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       if constexpr (REF == RF_GMM) gmm_resp<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, resp);
 #endif
       if constexpr (REF == RF_GMM_BIG) gmm_score<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, rs);
-      __builtin_amdgcn_sched_barrier(0);
       float st = 1.0f;
       if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[k] : 1.0f;
 
@@ -209,7 +207,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
   const float* bias = a.wpack + sd_off_bias(NT);
   const int p = lane & 15, g = lane >> 4;
   float* trash = a.trash + tid * 4;
-  for (int tile = blockIdx.x * SD_WAVES + wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {
+  for (int tile = blockIdx.x + gridDim.x * wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {  // CUs first
     const uint32_t row = static_cast<uint32_t>(tile) * 16u + p;
     const bool live = row < static_cast<uint32_t>(a.B);
     f32x4 x[NT];

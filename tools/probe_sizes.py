@@ -14,7 +14,7 @@ if alt:
 import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
-for (B, N, K) in [(65536, 64, 4), (65536, 256, 4), (131072, 256, 4), (65536, 256, 16)]:
+for (B, N, K) in [(2048, 100, 4), (65536, 64, 4), (65536, 256, 4), (131072, 256, 4), (65536, 256, 16)]:
     loss, ts, x0, args, parts, fl = bench.build_rds_gmm(dev, B, N, K=K)
     ev = L.HipEvents()
     loss.timing_events = ev
