@@ -4,90 +4,130 @@
 // The reference evaluates, per step, the drift net twice and the annealed score twice, each target score being
 // an autograd pass (4 per step with ScoreCtrl).  (t_k, y_k) of step k is (s_{k+1}, x_{k+1}) of step k+1 and the
 // control and the drift use the same target score, so ONE evaluation per step suffices; it is carried in
-// registers.  An evaluation is three FP32-MFMA chains: the drift net, logits = X w (+c) -> residual -> X^T r
-// (design matrix once in LDS, read in both orientations), and the prior score -P (y - mu).
+// registers.  An evaluation is four split-f16 MFMA chains that share one split of the state: the drift net,
+// logits = Xa w -> residual y - sigmoid -> Xa^T r (the augmented design matrix sits in LDS in both orientations as
+// packed A operands), and the prior score -P (w - mu) (precision matrix read through L2: LDS is full).
 #pragma once
 #include "sim_device.hpp"
 
 struct CmcdArgs {
   SimArgs s;                // common fields (coef has N+1 rows: row k col 0 = ts[k])
-  const float* x_image;     // global copy of the LDS design-matrix image [SD_LR_ROWS][SD_LR_STRIDE] (col d-1 = 1)
-  const float* y_pad;       // [SD_LR_ROWS] labels (0 on pad rows)
-  const float* prec_pack;   // packed prior precision (A operands, like a [d x d] layer) or nullptr (isotropic)
+  const float* lr_image;    // global copy of the two LDS images: logits image, then grad image (sd_lr_*_floats)
+  const float* y_pad;       // [32 * row K-blocks] labels (0 on pad rows)
+  const float* prec_pack;   // packed prior precision (A operands of a [d x d] layer, split f16) or nullptr (isotropic)
   const float* prior_loc;   // [16*NT] prior mean (0-padded)
-  float w_scale2, c_mean, c_scale2, thr;   // weight_scale^2, intercept_mean, intercept_scale^2, threshold
-  float iso_loc, iso_var;   // isotropic prior
-  int n_tiles_rows;         // data-row tiles actually populated (ceil(n/16))
+  float inv_w_scale2, c_mean, inv_c_scale2;   // 1/weight_scale^2, intercept_mean, 1/intercept_scale^2
+  float p_lo, p_hi;         // sigmoid range with non-zero gradient (clip threshold and eps clamp)
+  float iso_loc, inv_iso_var;   // isotropic prior
+  int n_rows;               // data rows n
 };
 
-__host__ __device__ inline int cmcd_lds_floats(int NT, bool full_prior) {
-  return sd_lds_weight_floats(NT) + SD_LR_ROWS * SD_LR_STRIDE + (full_prior ? NT * NT * 256 : 0);
+__host__ __device__ inline int cmcd_lds_floats(int NT, int n_rows) {
+  return sd_lds_weight_floats(NT) + sd_lr_logit_floats(NT, n_rows) + sd_lr_grad_floats(NT, n_rows);
 }
 
 // (u, b) at (time index ki, state x): u = ctrl(t, x) (reparam.py:112-117), b = annealed drift (eq/sdes.py:101-110)
 template <int NT>
 SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float w_t, float w_1mt, const float* lds,
                          const float* bias, int lane, f32x4 (&u)[NT], f32x4 (&b)[NT]) {
+  constexpr int KB = (NT + 1) / 2;
   const int g = lane >> 4;
   const SimArgs& s = a.s;
-  const float* xim = lds + sd_lds_weight_floats(NT);
-  // ---- target score: prior part + X^T r ----
-  f32x4 ts[NT];
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  const f16x8* im_logit = reinterpret_cast<const f16x8*>(lds + sd_lds_weight_floats(NT));
+  const f16x8* im_grad = reinterpret_cast<const f16x8*>(lds + sd_lds_weight_floats(NT) + sd_lr_logit_floats(NT, a.n_rows));
+  const int row_kb = sd_lr_row_kb(a.n_rows), row_tiles = sd_lr_row_tiles(a.n_rows);
+  // the LDS images never change inside the step loop; without a barrier the compiler hoists their reads out of
+  // it and keeps the A operands in (spilled) registers
+  asm volatile("" ::: "memory");
+  f16x8 xh[KB], xl[KB];
+  split_tiles<NT>(x, xh, xl);
+
+  // ---- target score: prior part of the posterior + Xa^T r ----
+  f32x4 ts[NT], tm[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = feat(t, r, g);
       const float xv = x[t][r];
-      float v = -xv / a.w_scale2;                                  // logistic_regression.py:72
-      v = (f == s.d - 1) ? -(xv - a.c_mean) / a.c_scale2 : v;      // :74
+      float v = -xv * a.inv_w_scale2;                                   // logistic_regression.py:72
+      v = (f == s.d - 1) ? -(xv - a.c_mean) * a.inv_c_scale2 : v;       // :74
       ts[t][r] = (f < s.d) ? v : 0.0f;
     }
-  for (int nt = 0; nt < a.n_tiles_rows; nt += 2) {  // two 16-row tiles of the design matrix per pass
-    f32x4 lg[2];
-    lg[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    lg[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    dense_plain<NT, 2, 0>(x, lg, xim, lane, 0, nt);               // logits of 32 data rows (intercept via the 1-column)
+    tm[t] = zero;
+  }
+  for (int pr = 0; pr < row_kb; ++pr) {  // 32 data rows per pass = one K-block of the Xa^T r product
+    asm volatile("" ::: "memory");
+    f32x4 lg[2], lm[2];
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
-      const f32x4 yv = load_tile4(a.y_pad, nt + o, g);
+      lg[o] = zero;
+      lm[o] = zero;
+      const int tile = 2 * pr + o;
+      if (tile < row_tiles) {  // wave-uniform
+        f32x4 acc[1] = {zero}, mx[1] = {zero};
+        dense_pre<KB, 1>(xh, xl, acc, mx, im_logit + static_cast<size_t>(tile) * KB * 2 * 64, lane);
+        lg[o] = acc[0];
+        lm[o] = mx[0];
+      }
+      const f32x4 yv = load_tile4(a.y_pad, tile, g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lg[o][r] = logreg_residual(lg[o][r], yv[r], a.thr);
+      for (int r = 0; r < 4; ++r)
+        lg[o][r] = logreg_residual(__builtin_fmaf(lm[o][r], SD_LO_INV, lg[o][r]), yv[r], a.p_lo, a.p_hi);  // pad rows: Xa row = 0
     }
-    dense_plain<2, NT, 1>(lg, ts, xim, lane, nt, 0);              // ts += X^T r (pad rows of X are zero)
+    f16x8 rh, rl;
+    split8(lg[0], lg[1], rh, rl);
+#pragma unroll
+    for (int to = 0; to < NT; ++to) {
+      const f16x8 ah = im_grad[((to * row_kb + pr) * 2 + 0) * 64 + lane];
+      const f16x8 al = im_grad[((to * row_kb + pr) * 2 + 1) * 64 + lane];
+      ts[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rh, ts[to], 0, 0, 0);
+      tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rl, tm[to], 0, 0, 0);
+      tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, rh, tm[to], 0, 0, 0);
+    }
   }
-  // ---- prior score ----
-  f32x4 ps[NT];
-  if (a.prec_pack) {  // GaussFull: -P (x - mu)   distr/gauss.py:129-135
-    f32x4 df[NT];
+  fold_lo<NT>(ts, tm);
+
+  // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
+  const float hg2 = 0.5f * (s.cmcd_g * s.cmcd_g);
+  if (a.prec_pack) {  // GaussFull: -P (w - mu)   distr/gauss.py:129-135
+    f32x4 df[NT], ps[NT], pm[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       df[t] = x[t] - load_tile4(a.prior_loc, t, g);
-      ps[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      ps[t] = zero;
+      pm[t] = zero;
     }
-    dense_f32<NT, NT>(df, ps, xim + SD_LR_ROWS * SD_LR_STRIDE, lane);
+    f16x8 dh[KB], dl[KB];
+    split_tiles<NT>(df, dh, dl);
+    dense_pre<KB, NT>(dh, dl, ps, pm, reinterpret_cast<const f16x8*>(a.prec_pack), lane);
+    fold_lo<NT>(ps, pm);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) ps[t] = -ps[t];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[t][r] = ts[t][r] * w_t + (-ps[t][r]) * w_1mt;
   } else {  // IsotropicGauss.score  distr/gauss.py:764-766
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ps[t][r] = (feat(t, r, g) < s.d) ? (a.iso_loc - x[t][r]) / a.iso_var : 0.0f;
+      for (int r = 0; r < 4; ++r) {
+        const float pv = feat_lt(t, r, 4 * g, s.d) ? (a.iso_loc - x[t][r]) * a.inv_iso_var : 0.0f;
+        b[t][r] = ts[t][r] * w_t + pv * w_1mt;
+      }
   }
-  // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
-  const float hg2 = 0.5f * (s.cmcd_g * s.cmcd_g);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = ts[t][r] * w_t + ps[t][r] * w_1mt;
-      v = v * hg2;
+      float v = b[t][r] * hg2;
       if (s.cmcd_clip > 0.0f) v = clampf(v, s.cmcd_clip);
       b[t][r] = v;
     }
+
   // ---- control ----
   f32x4 hid[SD_HT];
-  mlp_hidden<NT>(x, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane);
+  mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane);
   const float st = s.stheta ? s.stheta[ki] : 1.0f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -119,18 +159,14 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
   {
     const int nw = sd_lds_weight_floats(NT);
     for (int i = tid; i < nw / 4; i += SD_THREADS) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(s.wpack)[i];
-    float* xim = lds + nw;
-    for (int i = tid; i < SD_LR_ROWS * SD_LR_STRIDE; i += SD_THREADS) xim[i] = a.x_image[i];
-    if (a.prec_pack) {
-      float* pp = xim + SD_LR_ROWS * SD_LR_STRIDE;
-      for (int i = tid; i < NT * NT * 256; i += SD_THREADS) pp[i] = a.prec_pack[i];
-    }
+    const int ni = sd_lr_logit_floats(NT, a.n_rows) + sd_lr_grad_floats(NT, a.n_rows);
+    for (int i = tid; i < ni / 4; i += SD_THREADS) reinterpret_cast<f32x4*>(lds + nw)[i] = reinterpret_cast<const f32x4*>(a.lr_image)[i];
   }
   __syncthreads();
   const float* bias = s.wpack + sd_off_bias(NT);
   const int p = lane & 15, g = lane >> 4;
   float* trash = s.trash + tid * 4;
-  const float gg = s.cmcd_g;
+  const float gg = s.cmcd_g, inv_g = 1.0f / s.cmcd_g;
 
   for (int tile = blockIdx.x + gridDim.x * wave; tile < s.ntiles; tile += gridDim.x * SD_WAVES) {  // CUs first
     const uint32_t row = static_cast<uint32_t>(tile) * 16u + p;
@@ -148,7 +184,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
       const float* cf = s.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float dt = cf[2], sqdt = cf[3];
       // y = x + (b_s + u_s g) dt + g db ,  db = sqrt(dt) z      (losses/oc.py:722-724)
-      f32x4 y[NT], db[NT];
+      f32x4 db[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         f32x4 z;
@@ -163,18 +199,18 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
         for (int r = 0; r < 4; ++r) {
           const float dbv = sqdt * z[r];
           db[t][r] = dbv;
-          y[t][r] = x[t][r] + (b_s[t][r] + u_s[t][r] * gg) * dt + gg * dbv;
+          x[t][r] = x[t][r] + (b_s[t][r] + u_s[t][r] * gg) * dt + gg * dbv;
         }
       }
       f32x4 u_t[NT], b_t[NT];
-      cmcd_eval<NT>(a, y, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t);
+      cmcd_eval<NT>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t);
       // cost = (b_s + b_t)/g + u_s - u_t ;  rnd += 0.5 |cost|^2 dt + <cost, db>   (losses/oc.py:737-742)
       float c2 = 0.0f, cdb = 0.0f;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float c = ((b_s[t][r] + b_t[t][r]) / gg + u_s[t][r]) - u_t[t][r];
+          const float c = ((b_s[t][r] + b_t[t][r]) * inv_g + u_s[t][r]) - u_t[t][r];
           c2 = __builtin_fmaf(c, c, c2);
           cdb = __builtin_fmaf(c, db[t][r], cdb);
         }
@@ -184,7 +220,6 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
       rnd += cdb;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        x[t] = y[t];
         u_s[t] = u_t[t];
         b_s[t] = b_t[t];
       }
@@ -197,7 +232,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
 
 template <int NT>
 static int launch_cmcd(const CmcdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(cmcd_lds_floats(NT, a.prec_pack != nullptr)) * sizeof(float);
+  const size_t lds_bytes = static_cast<size_t>(cmcd_lds_floats(NT, a.n_rows)) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);

@@ -16,7 +16,7 @@
 int sd_launch_cmcd_1(const CmcdArgs& a, int grid, hipStream_t s);
 int sd_launch_cmcd_2(const CmcdArgs& a, int grid, hipStream_t s);
 int sd_launch_cmcd_4(const CmcdArgs& a, int grid, hipStream_t s);
-int sd_launch_logreg_image(const float* X, const float* y, int n, int dw, float* image, float* y_pad, hipStream_t s);
+int sd_launch_logreg_images(const float* X, const float* y, int n, int dw, int NT, float* image, float* y_pad, hipStream_t s);
 int sd_launch_pack_square(const float* P, const float* loc, int d, int NT, float* out, float* loc_pad, hipStream_t s);
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };
@@ -98,7 +98,10 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.trash = o; o += align64(SD_THREADS * 4);
   L.logz = o; o += align64(5 * SD_LOGZ_MAX_BLOCKS);
   L.cmcd = o;
-  if (d->form == SDENG_FORM_CMCD) o += align64(SD_LR_ROWS * SD_LR_STRIDE) + align64(SD_LR_ROWS) + align64(DT * DT * 256) + align64(16 * DT);
+  if (d->form == SDENG_FORM_CMCD) {
+    const int n = d->target.k > 0 ? d->target.k : 0;
+    o += align64(sd_lr_logit_floats(DT, n) + sd_lr_grad_floats(DT, n)) + align64(32 * sd_lr_row_kb(n)) + align64(DT * sd_kb(DT) * 512) + align64(16 * DT);
+  }
   L.total = o;
   return true;
 }
@@ -229,7 +232,11 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   const int dpad = 16 * DT;
   if (DT > 4) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: d <= 64 (got %d)", d->d);
   if (d->target.kind != SDENG_DIST_LOGREG) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: target must be LOGREG (kind %d)", d->target.kind);
-  if (d->target.k > SD_LR_ROWS) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: at most %d data rows (got %d)", SD_LR_ROWS, d->target.k);
+  const int n = d->target.k;
+  if (n < 1) return fail(SDENG_E_INVALID, "CMCD kernel: logistic regression without data rows");
+  if (static_cast<size_t>(cmcd_lds_floats(DT, n)) * sizeof(float) > 160 * 1024)
+    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: drift net + design matrix (%d rows x %d) need %zu bytes of LDS, 163840 available", n, d->d,
+                static_cast<size_t>(cmcd_lds_floats(DT, n)) * sizeof(float));
   if (d->prior.kind != SDENG_DIST_GAUSS_FULL && d->prior.kind != SDENG_DIST_ISO_GAUSS)
     return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: prior must be GAUSS_FULL or ISO_GAUSS (kind %d)", d->prior.kind);
   if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && d->net.ctrl_kind != SDENG_CTRL_SCORE)
@@ -246,18 +253,22 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   CmcdArgs c;
   memset(&c, 0, sizeof(c));
   float* image = ws + L.cmcd;
-  float* y_pad = image + align64(SD_LR_ROWS * SD_LR_STRIDE);
-  float* prec = y_pad + align64(SD_LR_ROWS);
-  float* locp = prec + align64(DT * DT * 256);
-  SD_HIP(sd_launch_logreg_image(d->target.loc, d->target.scale, d->target.k, d->d - 1, image, y_pad, s));
-  c.x_image = image; c.y_pad = y_pad;
-  c.n_tiles_rows = 2 * ((d->target.k + 31) / 32);  // 16-row tiles, processed in pairs
-  c.w_scale2 = d->target.p0 * d->target.p0; c.c_mean = d->target.p1; c.c_scale2 = d->target.p2 * d->target.p2; c.thr = d->target.p3;
+  float* y_pad = image + align64(sd_lr_logit_floats(DT, n) + sd_lr_grad_floats(DT, n));
+  float* prec = y_pad + align64(32 * sd_lr_row_kb(n));
+  float* locp = prec + align64(DT * sd_kb(DT) * 512);
+  SD_HIP(sd_launch_logreg_images(d->target.loc, d->target.scale, n, d->d - 1, DT, image, y_pad, s));
+  c.lr_image = image; c.y_pad = y_pad; c.n_rows = n;
+  c.inv_w_scale2 = 1.0f / (d->target.p0 * d->target.p0); c.c_mean = d->target.p1; c.inv_c_scale2 = 1.0f / (d->target.p2 * d->target.p2);
+  {  // sigmoid range with a gradient: inside clip(thr, 1 - thr) and inside the eps clamp of probs_to_logits
+    const float thr = d->target.p3, eps = 1.1920928955078125e-07f;
+    c.p_lo = thr > eps ? thr : eps;
+    c.p_hi = (1.0f - thr) < (1.0f - eps) ? (1.0f - thr) : (1.0f - eps);
+  }
   if (d->prior.kind == SDENG_DIST_GAUSS_FULL) {
     SD_HIP(sd_launch_pack_square(d->prior.scale, d->prior.loc, d->d, DT, prec, locp, s));
     c.prec_pack = prec; c.prior_loc = locp;
   } else {
-    c.iso_loc = d->prior.p0; c.iso_var = d->prior.p3;
+    c.iso_loc = d->prior.p0; c.inv_iso_var = 1.0f / d->prior.p3;
   }
   DistEvalArgs e;
   e.ds = prior; e.B = d->B; e.d = d->d; e.dpad = dpad; e.x = d->x_in; e.logp_out = ws + L.rnd_init; e.score_out = nullptr;

@@ -32,28 +32,6 @@ SD_INLINE bool feat_lt(int t, int r, int g4, int d) { return g4 < d - (16 * t + 
 SD_INLINE f32x4 load_tile4(const float* base, int t, int g) { return *reinterpret_cast<const f32x4*>(base + 16 * t + 4 * g); }
 
 // ----------------------------------------------------------------------------------------------
-// FP32 MFMA dense layer:  out[to] += W[to-tile][ti-tile] * in[ti]   (Y^T = W X^T form)
-// `w` is the LDS image written by k_pack_mlp: float4 index (to*TI+ti)*64+lane holds the A operands of the four
-// k-steps of that tile pair, W[16 to + (lane&15)][feat(ti, r, lane>>4)], r = 0..3.
-// v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain (1e-5 parity rules out bf16/xf32 paths); consecutive MFMAs
-// go to different accumulators (dependent latency 40 cycles vs 32-cycle issue).
-// ----------------------------------------------------------------------------------------------
-template <int TI, int TO>
-SD_INLINE void dense_f32(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* w, int lane) {
-  const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
-#pragma unroll
-  for (int ti = 0; ti < TI; ++ti) {
-    f32x4 a[TO];
-#pragma unroll
-    for (int to = 0; to < TO; ++to) a[to] = w4[(to * TI + ti) * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int to = 0; to < TO; ++to) out[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[to][r], in[ti][r], out[to], 0, 0, 0);
-  }
-}
-
-// ----------------------------------------------------------------------------------------------
 // Split-f16 dense layer on the f16 matrix pipe (v_mfma_f32_16x16x32_f16, fp32 accumulate).
 //
 // Why: on gfx950 an MFMA and vector instructions of the waves sharing a SIMD do not overlap (microbenchmark
@@ -115,6 +93,40 @@ SD_INLINE void dense(const f32x4 (&in)[NTI], f32x4 (&out)[TO], const float* w, i
     for (int r = 0; r < 4; ++r) out[to][r] = __builtin_fmaf(mx[to][r], SD_LO_INV, out[to][r]);
 }
 
+// The same product with the activations already split (all K-blocks at once): used where one split feeds several
+// products (CMCD: drift net, data logits and prior score all read the state).  `w8` may point to LDS or global.
+template <int KB, int TO>
+SD_INLINE void dense_pre(const f16x8 (&xh)[KB], const f16x8 (&xl)[KB], f32x4 (&out)[TO], f32x4 (&mx)[TO], const f16x8* w8, int lane) {
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    f16x8 ah[TO], al[TO];
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+      ah[to] = w8[((to * KB + kb) * 2 + 0) * 64 + lane];
+      al[to] = w8[((to * KB + kb) * 2 + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int to = 0; to < TO; ++to) out[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[to], xh[kb], out[to], 0, 0, 0);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) mx[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[to], xl[kb], mx[to], 0, 0, 0);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) mx[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[to], xh[kb], mx[to], 0, 0, 0);
+  }
+}
+template <int TO>
+SD_INLINE void fold_lo(f32x4 (&out)[TO], const f32x4 (&mx)[TO]) {
+#pragma unroll
+  for (int to = 0; to < TO; ++to)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[to][r] = __builtin_fmaf(mx[to][r], SD_LO_INV, out[to][r]);
+}
+template <int NT>
+SD_INLINE void split_tiles(const f32x4 (&x)[NT], f16x8 (&xh)[(NT + 1) / 2], f16x8 (&xl)[(NT + 1) / 2]) {
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int kb = 0; kb < (NT + 1) / 2; ++kb) split8(x[2 * kb], (2 * kb + 1 < NT) ? x[2 * kb + 1 < NT ? 2 * kb + 1 : 0] : zero, xh[kb], xl[kb]);
+}
+
 // GELU for the step loop: one branch-free piece, 8 fma + exp2 + max + fma (the erf form above costs 2 polynomial
 // pieces, a select and a sign transfer per element; the hidden layers apply 192 GELUs per particle-step and
 // vector issue slots, not the matrix pipe, bound the kernel).  With P(t) = log2( Phi(-t) ) = log2(erfc(t/sqrt2)/2),
@@ -164,6 +176,30 @@ SD_INLINE void mlp_hidden(const f32x4 (&x)[NT], f32x4 (&a)[SD_HT], const float* 
   dense<NT, SD_HT>(x, a, lds + sd_off_win(NT), lane);
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) a[t] = a[t] + load_tile4(temb, t, g);  // embed = embed_x + embed_t
+  gelu_tiles<SD_HT>(a);
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) b[t] = load_tile4(bias + 64, t, g);  // b_h1
+  dense<SD_HT, SD_HT>(a, b, lds + sd_off_wh1(NT), lane);
+  gelu_tiles<SD_HT>(b);
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias + 128, t, g);  // b_h2
+  dense<SD_HT, SD_HT>(b, a, lds + sd_off_wh2(NT), lane);
+  gelu_tiles<SD_HT>(a);
+}
+
+// mlp_hidden with the input layer fed from a pre-split state
+template <int NT>
+SD_INLINE void mlp_hidden_pre(const f16x8 (&xh)[(NT + 1) / 2], const f16x8 (&xl)[(NT + 1) / 2], f32x4 (&a)[SD_HT], const float* lds,
+                              const float* bias, const float* temb, int lane) {
+  const int g = lane >> 4;
+  f32x4 b[SD_HT], mx[SD_HT];
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) {
+    a[t] = load_tile4(bias, t, g) + load_tile4(temb, t, g);  // b_in + embed_t
+    mx[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  dense_pre<(NT + 1) / 2, SD_HT>(xh, xl, a, mx, reinterpret_cast<const f16x8*>(lds + sd_off_win(NT)), lane);
+  fold_lo<SD_HT>(a, mx);
   gelu_tiles<SD_HT>(a);
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) b[t] = load_tile4(bias + 64, t, g);  // b_h1
@@ -449,40 +485,24 @@ SD_INLINE void store_rows(float* __restrict__ dst, float* __restrict__ trash, ui
 // ----------------------------------------------------------------------------------------------
 // CMCD building blocks (eq/sdes.py:101-110, distr/logistic_regression.py, distr/gauss.py:129-135)
 // ----------------------------------------------------------------------------------------------
-#define SD_LR_ROWS 192      // data rows padded to 12 tiles of 16 (sonar: 166)
-#define SD_LR_STRIDE 65     // LDS row stride of the design-matrix image (odd: at most 2-way conflicts both ways)
+// Logistic-regression data for the CMCD kernel live in LDS as two packed split-f16 A-operand images of the
+// augmented design matrix Xa = [X | 1] (the ones column carries the intercept, logistic_regression.py:52-55):
+//   logits image: blocks [row tile][feature K-block]   (out = data rows, sum over features)      logits = Xa w
+//   grad   image: blocks [feature tile][row K-block]    (out = features,  sum over data rows)     grad   = Xa^T r
+// both in the (to, kb, part, lane, 8 halves) layout of k_pack_mlp; data rows are padded with zero rows.
+__host__ __device__ inline int sd_lr_row_tiles(int n) { return (n + 15) / 16; }
+__host__ __device__ inline int sd_lr_row_kb(int n) { return (n + 31) / 32; }
+__host__ __device__ inline int sd_lr_logit_floats(int NT, int n) { return sd_lr_row_tiles(n) * sd_kb(NT) * 512; }
+__host__ __device__ inline int sd_lr_grad_floats(int NT, int n) { return NT * sd_lr_row_kb(n) * 512; }
 
-// Dense product whose A operands come from ONE plain LDS image M[rows][SD_LR_STRIDE] (ds_read_b32 per k-step):
-//   TRANS = 0: out[to] += M[16 (to+out0) + i][feat(ti+in0, r, g)]      (rows = outputs)      logits = X w
-//   TRANS = 1: out[to] += M[feat(ti+in0, r, g)][16 (to+out0) + i]      (rows = summation)    grad   = X^T r
-// so the design matrix is stored once and read in both orientations.
-template <int TI, int TO, int TRANS>
-SD_INLINE void dense_plain(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* m, int lane, int in0, int out0) {
-  const int i = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int to = 0; to < TO; ++to) {
-        const int kf = 16 * (ti + in0) + 4 * g + r;
-        const int o = 16 * (to + out0) + i;
-        const float a = TRANS ? m[kf * SD_LR_STRIDE + o] : m[o * SD_LR_STRIDE + kf];
-        out[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, in[ti][r], out[to], 0, 0, 0);
-      }
-}
-
-// Per-datum factor of the logistic-regression score the reference obtains by autograd through
-// sigmoid -> clip(thr) -> probs_to_logits(clamp eps) -> BCE-with-logits (distr/logistic_regression.py:41-61,
-// distr/base.py:146-154); closed form checked against autograd incl. saturated rows.
-SD_INLINE float logreg_residual(float logit, float y, float thr) {
-  const float eps = 1.1920928955078125e-07f;
-  const float p = 1.0f / (1.0f + expf(-logit));
-  const float pc = fminf(fmaxf(p, thr), 1.0f - thr);
-  const float pcc = fminf(fmaxf(pc, eps), 1.0f - eps);
-  const bool pass = (p >= thr) && (p <= 1.0f - thr) && (pc >= eps) && (pc <= 1.0f - eps);
-  const float l2 = logf(pcc) - log1pf(-pcc);
-  const float sg = 1.0f / (1.0f + expf(-l2));
-  const float r = (y - sg) * (1.0f / pcc + 1.0f / (1.0f - pcc)) * (p * (1.0f - p));
-  return pass ? r : 0.0f;
+// Per-datum factor of the logistic-regression score.  The reference differentiates
+// sigmoid -> clip(thr) -> probs_to_logits(clamp eps) -> BCE-with-logits by autograd
+// (distr/logistic_regression.py:41-61, distr/base.py:146-154).  With p = sigmoid(logit) inside both clamps the
+// chain collapses: logits2 = logit(p), sigmoid(logits2) = p and d logits2/dp * dp/dlogit = 1, so the factor is
+// y - p; outside a clamp the gradient is zero.  (k_dist_eval keeps the long form; the two agree to fp32
+// round-off, tests/test_gpu_units.py.)
+SD_INLINE float logreg_residual(float logit, float y, float p_lo, float p_hi) {
+  const float e = __builtin_amdgcn_exp2f(logit * -1.4426950408889634f);
+  const float p = __builtin_amdgcn_rcpf(1.0f + e);
+  return (p >= p_lo && p <= p_hi) ? (y - p) : 0.0f;
 }
