@@ -361,19 +361,33 @@ __device__ void dist_score_row(const DistEvalArgs& a, const float* x, float* sc)
   }
 }
 
+// One thread per particle, but the block's 64 rows are brought in with coalesced loads and parked in LDS with an
+// odd row stride (thread t then walks row t conflict-free); a thread reading its own row straight from HBM touches
+// 64 different cache lines per wave-instruction.
+__device__ inline const float* stage_rows(const float* x, int B, int d, float* sh) {
+  const int row0 = blockIdx.x * blockDim.x, stride = d | 1;
+  const int n = (B - row0 < static_cast<int>(blockDim.x) ? B - row0 : static_cast<int>(blockDim.x)) * d;
+  const float* src = x + static_cast<size_t>(row0) * d;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sh[(i / d) * stride + (i % d)] = src[i];
+  __syncthreads();
+  return sh + threadIdx.x * stride;
+}
+
 __global__ void k_dist_eval(DistEvalArgs a) {
+  extern __shared__ float sh[];
+  const float* x = stage_rows(a.x, a.B, a.d, sh);
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= a.B) return;
-  const float* x = a.x + static_cast<size_t>(row) * a.d;
   if (a.logp_out) a.logp_out[row] = dist_logp_row(a, x);
   if (a.score_out) dist_score_row(a, x, a.score_out + static_cast<size_t>(row) * a.d);
 }
 
 // terminal cost, in place on rnd (losses/oc.py:290: rnd += ref_logp(x) - target_logp(x); :973: rnd -= target_logp(x))
 __global__ void k_terminal(TerminalArgs a) {
+  extern __shared__ float sh[];
+  const float* x = stage_rows(a.x, a.B, a.d, sh);
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= a.B) return;
-  const float* x = a.x + static_cast<size_t>(row) * a.d;
   float term = 0.0f;
   if (a.use_ref) {
     DistEvalArgs e;
@@ -508,11 +522,11 @@ int sd_launch_dist_tables(const DistTabArgs& a, hipStream_t s) {
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_dist_eval(const DistEvalArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_dist_eval, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_dist_eval, dim3((a.B + 63) / 64), dim3(64), 64 * (a.d | 1) * sizeof(float), s, a);
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_terminal(const TerminalArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_terminal, dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_terminal, dim3((a.B + 63) / 64), dim3(64), 64 * (a.d | 1) * sizeof(float), s, a);
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_logz(const float* rnd, long long B, float* stats, float* weights, float* scratch, hipStream_t s) {

@@ -418,6 +418,7 @@ extern "C" int sdeng_dist_eval(const sdeng_dist* dist, int32_t B, int32_t d, con
                                void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!dist || !x || d < 1 || B < 0) return fail(SDENG_E_INVALID, "bad argument");
+  if (d > 255) return fail(SDENG_E_UNSUPPORTED, "dist_eval: d <= 255 (rows are staged through LDS), got %d", d);
   if (B == 0) return 0;
   const int dpad = 16 * ((d + 15) / 16);
   const size_t need = dist_floats(*dist, dpad) * sizeof(float);
