@@ -81,17 +81,18 @@ extern "C" {
 #define SDENG_DIST_PHI4 4       /* distr/phi_four.py:8-96  1-D lattice, Dirichlet-0 boundary                */
 #define SDENG_DIST_LOGREG 5     /* distr/logistic_regression.py:11-92 + autograd score distr/base.py:146-154 */
 #define SDENG_DIST_GAUSS_FULL 6 /* distr/gauss.py:632-717  GaussFull (MultivariateNormal)                   */
+#define SDENG_DIST_RINGS 7      /* distr/rings.py:38-109   2-D rings: radial Gaussian mixture x uniform angle     */
 
 typedef struct sdeng_dist {
   int32_t kind;      /* SDENG_DIST_*                                                              */
   int32_t k;         /* GMM: number of components; LOGREG: number of data rows                    */
-  const float* loc;  /* GMM [k,d]; GAUSS_DIAG/GAUSS_FULL [d]; LOGREG: X [k,d-1]                   */
+  const float* loc;  /* GMM [k,d]; GAUSS_DIAG/GAUSS_FULL [d]; LOGREG: X [k,d-1]; RINGS: radii [k <= 8]  */
   const float* scale;/* GMM [k,d]; GAUSS_DIAG [d] (std-dev); GAUSS_FULL: precision [d,d]; LOGREG: y [k] */
-  const float* w;    /* GMM: unnormalised mixture weights [k]; GAUSS_FULL: inverse Cholesky factor L^-1 [d,d] */
+  const float* w;    /* GMM, RINGS: unnormalised mixture weights [k]; GAUSS_FULL: inverse Cholesky factor L^-1 [d,d] */
   float p0, p1, p2, p3; /* ISO_GAUSS: loc, scale, norm_const = -0.5*d*log(2*pi*scale^2), scale^2 (both as the
                            reference computes them in fp32, distr/gauss.py:759-760); PHI4: a, b, beta;
                            LOGREG: weight_scale, intercept_mean, intercept_scale, threshold;
-                           GAUSS_FULL: p0 = sum(log diag L) */
+                           GAUSS_FULL: p0 = sum(log diag L); RINGS: p0 = radial std-dev (d must be 2) */
   float clip;        /* clip applied to the log-density (solver/oc.py:80-87 clip_target); <=0: none */
 } sdeng_dist;
 

@@ -285,6 +285,23 @@ __device__ float dist_logp_row(const DistEvalArgs& a, const float* x) {
     }
     out = ll + prior;
   }
+  else if (ds.kind == SDENG_DIST_RINGS) {
+    // distr/rings.py:93-98: log MixtureSameFamily(Categorical(w), Normal(rad, scale))(r) + log Uniform(0,2pi) - log r
+    const float r = sqrtf(x[0] * x[0] + x[1] * x[1]);
+    float wsum = 0.0f;
+    for (int k = 0; k < ds.k; ++k) wsum += ds.aux1[k];
+    const float ls = logf(ds.p0), var = ds.p0 * ds.p0;
+    float m_run = -INFINITY, l_run = 0.0f;
+    for (int k = 0; k < ds.k; ++k) {
+      const float dl = r - ds.aux0[k];
+      // Normal.log_prob: -((v - loc)^2)/(2 var) - log(scale) - log(sqrt(2 pi))
+      const float lp = ((-(dl * dl) / (2.0f * var)) - ls) - 0.91893853320467274178f + logf(ds.aux1[k] / wsum);
+      const float m_new = fmaxf(m_run, lp);
+      l_run = l_run * expf(m_run - m_new) + expf(lp - m_new);
+      m_run = m_new;
+    }
+    out = ((m_run + logf(l_run)) - 1.8378770664093453f) - logf(r);
+  }
   if (ds.clip > 0.0f) out = clampf(out, ds.clip);
   return out;
 }
@@ -358,6 +375,10 @@ __device__ void dist_score_row(const DistEvalArgs& a, const float* x, float* sc)
       gc += r;
     }
     sc[dw] = gc;
+  } else if (ds.kind == SDENG_DIST_RINGS) {
+    const f32x4 r = rings_score(f32x4{x[0], x[1], 0.0f, 0.0f}, ds, 0);
+    sc[0] = r[0];
+    sc[1] = r[1];
   }
 }
 

@@ -148,6 +148,11 @@ static int build_dist(const sdeng_dist& in, int d, int dpad, float* ws, DistDev&
       if (!in.loc || !in.scale || in.k < 1) return fail(SDENG_E_INVALID, "LOGREG needs X, y and k >= 1 rows");
       out.aux0 = in.loc; out.aux1 = in.scale;
       return 0;
+    case SDENG_DIST_RINGS:
+      if (d != 2) return fail(SDENG_E_INVALID, "RINGS is two-dimensional (d = %d)", d);
+      if (!in.loc || !in.w || in.k < 1 || in.k > 8 || !(in.p0 > 0.0f)) return fail(SDENG_E_INVALID, "RINGS needs radii, weights, 1 <= k <= 8, scale > 0");
+      out.aux0 = in.loc; out.aux1 = in.w;
+      return 0;
     default:
       return fail(SDENG_E_UNSUPPORTED, "unknown distribution kind %d", in.kind);
   }
@@ -211,7 +216,7 @@ static int score_kind(const sdeng_desc* d, int& sc) {
   if (d->net.ctrl_kind == SDENG_CTRL_CLIPPED) return 0;
   if (d->net.ctrl_kind != SDENG_CTRL_SCORE && d->net.ctrl_kind != SDENG_CTRL_LERP)
     return fail(SDENG_E_UNSUPPORTED, "unknown ctrl_kind %d", d->net.ctrl_kind);
-  if (d->target.kind == SDENG_DIST_GMM_DIAG) sc = SC_GMM;
+  if (d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_RINGS) sc = SC_GMM;  // rings: runtime branch of the d <= 16 kernel
   else if (d->target.kind == SDENG_DIST_PHI4) sc = SC_PHI4;
   else return fail(SDENG_E_UNSUPPORTED, "ScoreCtrl/LerpCtrl: no in-loop score kernel for target kind %d", d->target.kind);
   if (d->net.ctrl_kind == SDENG_CTRL_LERP && d->prior.kind != SDENG_DIST_ISO_GAUSS)

@@ -398,6 +398,39 @@ SD_INLINE f32x4 gauss_score_tile(const f32x4 (&x)[NT], const float* __restrict__
   return out;
 }
 
+// Rings target (distr/rings.py:100-109), d = 2: both coordinates sit in registers 0,1 of the g = 0 lanes.
+//   n = |x| + eps;  score = x * (score_radius(n)/n - 1/n^2),  score_radius = score_mog over the radii (gauss.py:97-107)
+// Lanes of the other feature groups (g != 0) hold pad features -- which carry noise in Philox mode -- and return 0.
+SD_INLINE f32x4 rings_score(const f32x4& x, const DistDev& ds, int g) {
+  const float n = __builtin_sqrtf(x[0] * x[0] + x[1] * x[1]) + 1e-7f;
+  const float var = ds.p0 * ds.p0;
+  float wsum = 0.0f;
+  for (int k = 0; k < ds.k; ++k) wsum += ds.aux1[k];
+  const float cn = 0.5f * 1.8378770664093453f + 0.5f * logf(var);  // 0.5*1*log(2 pi) + 0.5*log(var)
+  float lp[8], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    lp[k] = -INFINITY;
+    if (k < ds.k) {
+      const float dl = n - ds.aux0[k];
+      lp[k] = logf(ds.aux1[k] / wsum) + ((-0.5f * ((dl * dl) / var)) - cn);
+      mx = fmaxf(mx, lp[k]);
+    }
+  }
+  float den = 0.0f, acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < ds.k) {
+      const float e = expf(lp[k] - mx);
+      den += e;
+      acc += e * ((n - ds.aux0[k]) / var);
+    }
+  }
+  const float sr = -(acc / den);
+  const float f = (sr / n) - (1.0f / (n * n));
+  return g == 0 ? f32x4{x[0] * f, x[1] * f, 0.0f, 0.0f} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
 // phi^4 lattice neighbours of tile t (sites 16 t + 4 g + 0..3).  Lane (p, g-1) holds the site left of the
 // group, lane (p, g+1) the site right of it; across a tile border they come from the neighbouring tile.
 template <int NT>

@@ -88,7 +88,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
       f32x4 ts[SC != SC_NONE ? NT : 1];
-      if constexpr (SC == SC_GMM) gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
+      if constexpr (SC == SC_GMM) {
+        if (NT == 1 && a.target.kind == SDENG_DIST_RINGS) ts[0] = rings_score(x[0], a.target, g);
+        else gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
+      }
       if constexpr (SC == SC_PHI4) phi4_score<NT>(x, a.target, d_dyn, g, lane, ts);
       // reference drift (eq/sdes.py:265-279, 329-345): small mixtures keep only the K responsibilities and
       // assemble the score tile by tile in the tail; larger ones use the online-softmax accumulator
@@ -216,7 +219,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
     f32x4 hid[SD_HT];
     mlp_hidden<NT>(x, hid, lds, bias, a.temb, lane);
     f32x4 ts[SC != SC_NONE ? NT : 1];
-    if constexpr (SC == SC_GMM) gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
+    if constexpr (SC == SC_GMM) {
+      if (NT == 1 && a.target.kind == SDENG_DIST_RINGS) ts[0] = rings_score(x[0], a.target, g);
+      else gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
+    }
     if constexpr (SC == SC_PHI4) phi4_score<NT>(x, a.target, a.d, g, lane, ts);
     float st = 1.0f;
     if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[0] : 1.0f;

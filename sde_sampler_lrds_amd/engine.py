@@ -94,6 +94,15 @@ def dist_desc(obj, device, keep, clip=None) -> L.Dist:
         ds.p0, ds.p1, ds.p2 = float(obj.weight_scale), float(obj.intercept_mean), float(obj.intercept_scale)
         ds.p3 = float(obj.threshold)
         return ds
+    if n == "Rings":  # distr/rings.py:38-109
+        ds.kind = L.DIST_RINGS
+        ds.k = int(obj.radiuses.shape[0])
+        if ds.k > 8:
+            raise UnsupportedByEngine("Rings: at most 8 radii")
+        ds.loc = _dev_f32(obj.radiuses, device, keep)
+        ds.w = _dev_f32(obj.radius_dist.mixture_distribution.probs, device, keep)
+        ds.p0 = float(obj.radius_dist.component_distribution.scale.reshape(-1)[0])
+        return ds
     raise UnsupportedByEngine(f"no HIP log-density/score for distribution {n}")
 
 

@@ -11,6 +11,7 @@ import torch
 
 from ..distr.gauss import ManyModes, TwoModes
 from ..distr.phi_four import PhiFour
+from ..distr.rings import Rings
 from ..solver import oc
 from ..utils.common import get_timesteps
 
@@ -37,6 +38,8 @@ def make_target_details(target_name, **kwargs):
                     mixture_weight_factor=kwargs.get("mixture_weight_factor", 3.0), var=kwargs.get("var", 0.5))
     if target_name == "phi_four":
         return dict(name="phi_four", dim=kwargs.get("dim", 100), b=kwargs.get("b", 0.0))
+    if target_name == "rings":
+        return dict(name="rings")
     raise NotImplementedError(f"Target {target_name} not supported by the HIP engine.")
 
 
@@ -49,6 +52,8 @@ def _make_target(details):
         return TwoModes(**{"dim": 2, "a": 1.0, "n_reference_samples": 10000, **d})
     if name == "phi_four":  # conf/target/phi_four.yaml
         return PhiFour(**{"dim": 100, "a": 0.1, "b": 0.0, "dim_phys": 1, "beta": 20.0, **d})
+    if name == "rings":  # conf/target/rings.yaml
+        return Rings(**{"dim": 2, "n_reference_samples": 10000, **d})
     if "object" in details:
         return details["object"]
     raise NotImplementedError(name)

@@ -10,6 +10,7 @@ from sde_sampler_lrds_amd.distr.delta import Delta
 from sde_sampler_lrds_amd.distr.gauss import GMM, Gauss, GaussFull, IsotropicGauss
 from sde_sampler_lrds_amd.distr.logistic_regression import LogisticRegression
 from sde_sampler_lrds_amd.distr.phi_four import PhiFour
+from sde_sampler_lrds_amd.distr.rings import Rings
 from sde_sampler_lrds_amd.eq.sdes import VP, ControlledLangevinSDE, PinnedBM, ScaledBM
 from sde_sampler_lrds_amd.losses import oc
 from sde_sampler_lrds_amd.models.mlp import FourierMLP, TimeEmbed
@@ -61,8 +62,12 @@ def build(c, device):
             mod.to(device)
         loss = oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
         out.update(loss=loss, args=(target.unnorm_log_prob, refd.log_prob), kwargs={})
-    elif kind == "dds":
-        target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
+    elif kind in ("dds", "dds_rings"):
+        if kind == "dds_rings":
+            target = Rings(dim=2, lower_rad=m["lower_rad"], upper_rad=m["upper_rad"], num_rad=m["num_rad"], scale=m["scale"],
+                           n_reference_samples=10)
+        else:
+            target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
         prior = IsotropicGauss(dim=d, scale=m["sigma"])
         ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
                          clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"])

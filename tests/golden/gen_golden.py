@@ -240,10 +240,14 @@ def case_pis_phi4(name, d, B, N, seed, dt):
     finish(name, meta, arrays, res, draws)
 
 
-def case_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0):
-    """DDS on TwoModes (conf/solver/dds.yaml, conf/loss/exponential_sde.yaml, solver/oc.py:438-452)."""
+def case_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0, rings=False):
+    """DDS on TwoModes or Rings (conf/solver/dds.yaml, conf/loss/exponential_sde.yaml, conf/target/rings.yaml,
+    solver/oc.py:438-452)."""
     torch.manual_seed(seed)
-    target = r_gauss.TwoModes(dim=d, a=1.0, ill_conditioned="not", n_reference_samples=10)
+    if rings:
+        target = r_rings.Rings(dim=2, n_reference_samples=10)
+    else:
+        target = r_gauss.TwoModes(dim=d, a=1.0, ill_conditioned="not", n_reference_samples=10)
     prior = r_gauss.IsotropicGauss(dim=d, scale=sigma)
     ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.01),
                            target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
@@ -256,10 +260,14 @@ def case_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0):
     (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
         ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=prior.log_prob,
         compute_ito_int=True))
-    meta = dict(kind="dds", d=d, B=B, N=len(ts) - 1, seed=seed, alpha=1.0, sigma=sigma, clip_model=1e4, clip_score=1e4,
-                scale_score=1.0, dt=dt, end=end)
-    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], tgt_loc=target.loc, tgt_scale=target.scale,
-                  tgt_w=target.mixture_weights, **pack_params("ctrl.", sd(ctrl)))
+    meta = dict(kind="dds_rings" if rings else "dds", d=d, B=B, N=len(ts) - 1, seed=seed, alpha=1.0, sigma=sigma, clip_model=1e4,
+                clip_score=1e4, scale_score=1.0, dt=dt, end=end)
+    if rings:
+        meta.update(lower_rad=1.0, upper_rad=5.0, num_rad=3, scale=0.1)
+        tgt_arrays = dict(rings_rad=target.radiuses, rings_w=target.radius_dist.mixture_distribution.probs)
+    else:
+        tgt_arrays = dict(tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], **tgt_arrays, **pack_params("ctrl.", sd(ctrl)))
     finish(name, meta, arrays, res, draws)
 
 
@@ -446,27 +454,38 @@ def unit_vectors():
     save("unit_vectors", dict(kind="unit", **meta), out)
 
 
-def main():
-    unit_vectors()
+CASES = {
+    "unit_vectors": unit_vectors,
     # config 2 family (ManyModes d=128, RDS gmm-ref, VP, EI)
-    case_rds_gmm("rds_ei_gmm_d128_k4", d=128, K=4, B=64, N=16, seed=11)
-    case_rds_gmm("rds_ei_gmm_d128_k4_n256", d=128, K=4, B=32, N=256, seed=12)
-    case_rds_gmm("rds_ei_gmm_d128_k16", d=128, K=16, B=32, N=32, seed=13)
-    case_rds_gmm("rds_ei_gmm_d8_k4", d=8, K=4, B=96, N=100, seed=14)
-    case_rds_gmm("rds_ddpm_gmm_d16_snr", d=16, K=4, B=64, N=32, seed=15, integrator="ddpm_like", time_type="snr")
-    case_rds_gmm("rds_em_gmm_d16", d=16, K=4, B=64, N=64, seed=16, integrator="em")
-    case_rds_default("rds_em_vp_default_d16", d=16, K=4, B=64, N=64, seed=17, sde_kind="vp", integrator="em")
-    case_rds_default("rds_ei_vp_default_d16", d=16, K=4, B=64, N=32, seed=18, sde_kind="vp", integrator="ei")
-    case_rds_default("rds_ei_pbm_default_d16", d=16, K=4, B=64, N=32, seed=19, sde_kind="pbm", integrator="ei")
+    "rds_ei_gmm_d128_k4": lambda n: case_rds_gmm(n, d=128, K=4, B=64, N=16, seed=11),
+    "rds_ei_gmm_d128_k4_n256": lambda n: case_rds_gmm(n, d=128, K=4, B=32, N=256, seed=12),
+    "rds_ei_gmm_d128_k16": lambda n: case_rds_gmm(n, d=128, K=16, B=32, N=32, seed=13),
+    "rds_ei_gmm_d8_k4": lambda n: case_rds_gmm(n, d=8, K=4, B=96, N=100, seed=14),
+    "rds_ddpm_gmm_d16_snr": lambda n: case_rds_gmm(n, d=16, K=4, B=64, N=32, seed=15, integrator="ddpm_like", time_type="snr"),
+    "rds_em_gmm_d16": lambda n: case_rds_gmm(n, d=16, K=4, B=64, N=64, seed=16, integrator="em"),
+    "rds_em_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=64, seed=17, sde_kind="vp", integrator="em"),
+    "rds_ei_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=18, sde_kind="vp", integrator="ei"),
+    "rds_ei_pbm_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=19, sde_kind="pbm", integrator="ei"),
     # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
-    case_pis_phi4("pis_em_phi4_d100", d=100, B=64, N=32, seed=21, dt=5.0 / 512)
-    # config 1 (TwoModes d=2, DDS)
-    case_dds("dds_two_modes_d2", d=2, B=128, seed=31)
+    "pis_em_phi4_d100": lambda n: case_pis_phi4(n, d=100, B=64, N=32, seed=21, dt=5.0 / 512),
+    # config 1 (TwoModes d=2, DDS) and the Rings target on the same solver
+    "dds_two_modes_d2": lambda n: case_dds(n, d=2, B=128, seed=31),
+    "dds_rings_d2": lambda n: case_dds(n, d=2, B=128, seed=32, rings=True),
     # config 4 (logreg d=61, CMCD), at the real step size 1/256
-    case_cmcd_logreg("cmcd_logreg_d61", B=64, N=16, seed=41, dt=1.0 / 256)
+    "cmcd_logreg_d61": lambda n: case_cmcd_logreg(n, B=64, N=16, seed=41, dt=1.0 / 256),
     # DIS variants
-    case_dis("dis_ei_d8", d=8, K=4, B=64, N=32, seed=51, kind="ei")
-    case_dis("dis_orig_lerp_d8", d=8, K=4, B=64, N=64, seed=52, kind="orig")
+    "dis_ei_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=51, kind="ei"),
+    "dis_orig_lerp_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=64, seed=52, kind="orig"),
+}
+
+
+def main():
+    """python tests/golden/gen_golden.py [case ...]   (default: every case)"""
+    for name in (sys.argv[1:] or list(CASES)):
+        if name == "unit_vectors":
+            unit_vectors()
+        else:
+            CASES[name](name)
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SIM_CASES = [
     "rds_ei_gmm_d128_k4", "rds_ei_gmm_d128_k4_n256", "rds_ei_gmm_d128_k16", "rds_ei_gmm_d8_k4",
     "rds_ddpm_gmm_d16_snr", "rds_em_gmm_d16", "rds_em_vp_default_d16", "rds_ei_vp_default_d16",
-    "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "cmcd_logreg_d61", "dis_ei_d8",
+    "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "dis_ei_d8",
     "dis_orig_lerp_d8",
 ]
 
@@ -95,8 +95,11 @@ def run_oracle(c: Case, noise=None, B=None):
                         clip_score=m["clip_score"], scale_score=m["scale_score"])
         refd = orc.GaussDiag(c["ref_loc"], c["ref_scale"])
         out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, None, noise)
-    elif kind == "dds":
-        tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+    elif kind in ("dds", "dds_rings"):
+        if kind == "dds_rings":
+            tgt = orc.Rings(m["lower_rad"], m["upper_rad"], m["num_rad"], m["scale"])
+        else:
+            tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
         prior = orc.IsoGauss(m["d"], 0.0, m["sigma"])
         ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score,
                         clip_score=m["clip_score"], scale_score=m["scale_score"])

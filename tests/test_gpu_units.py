@@ -10,6 +10,7 @@ from sde_sampler_lrds_amd import engine as E
 from sde_sampler_lrds_amd.distr.gauss import GMM, Gauss, GaussFull, IsotropicGauss
 from sde_sampler_lrds_amd.distr.logistic_regression import LogisticRegression
 from sde_sampler_lrds_amd.distr.phi_four import PhiFour
+from sde_sampler_lrds_amd.distr.rings import Rings
 from tests import build_cases as bc
 from tests import golden_cases as gc
 
@@ -31,6 +32,8 @@ def test_distribution_kernels_match_reference_vectors(gpu):
     m = c.meta["phi"]
     lp, sc = E.dist_eval(PhiFour(a=m["a"], b=m["b"], dim=m["dim"], beta=m["beta"]).to(gpu), c["phi_x"].to(gpu))
     assert gc.rel_err(lp.cpu(), c["phi_logp"]) < 2e-6 and gc.rel_err(sc.cpu(), c["phi_score"]) < 2e-6
+    lp, sc = E.dist_eval(Rings(n_reference_samples=10), c["rings_x"].to(gpu))  # reference defaults, distr/rings.py:41-51
+    assert gc.rel_err(lp.cpu(), c["rings_logp"]) < 1e-5 and gc.rel_err(sc.cpu(), c["rings_score"]) < 1e-5
 
 
 @pytest.mark.gpu
@@ -46,7 +49,7 @@ def test_logreg_kernel_matches_autograd_fixture(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["rds_ei_gmm_d128_k4", "pis_em_phi4_d100", "dds_two_modes_d2", "dis_orig_lerp_d8"])
+@pytest.mark.parametrize("name", ["rds_ei_gmm_d128_k4", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "dis_orig_lerp_d8"])
 def test_ctrl_forward_matches_oracle(gpu, name):
     """FP32-MFMA drift net + control wrapper at one time vs the oracle (mid-trajectory states)."""
     c = gc.load(name)
