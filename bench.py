@@ -7,7 +7,7 @@ A "step" of this bench = one full pass: all 256 SDE steps of the batch, terminal
 log-Z / ESS reduction (the window the reference times as eval/sample_time, solver/oc.py:148-158),
 inputs already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rds_ei_gmm|pis_phi4]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
 For N>1 launch with torch.distributed.run (one rank per GPU, RCCL): the particle batch is sharded
 (weak scaling: 65 536 particles per rank, Philox counters keyed by the global particle index), no
@@ -30,36 +30,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 (dense, = vector fp32 peak)
-
-
-def build_rds_gmm(device, B, N, d=128, K=4, seed=1):
-    from sde_sampler_lrds_amd.distr.gauss import ManyModes
-    from sde_sampler_lrds_amd.eq.sdes import VP
-    from sde_sampler_lrds_amd.losses.oc import EIReferenceSDELoss
-    from sde_sampler_lrds_amd.models.mlp import FourierMLP
-    from sde_sampler_lrds_amd.models.reparam import ClippedCtrl
-    from sde_sampler_lrds_amd.reference import MarginalReference
-    from sde_sampler_lrds_amd.utils.common import get_timesteps
-    torch.manual_seed(seed)
-    sde = VP(0.1, 10.0, 1.0, terminal_t=1.0)
-    target = ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
-    net = FourierMLP(dim=d, activation=torch.nn.GELU(), num_layers=4, channels=64)
-    with torch.no_grad():  # random-init weights of the reference architecture, last layer "alive"
-        net.out_layer.weight.uniform_(-0.1, 0.1)
-        net.out_layer.bias.uniform_(-0.1, 0.1)
-    ctrl = ClippedCtrl(base_model=net, clip_model=1e4)
-    means = target.loc.clone() + 0.1 * torch.randn(K, d)
-    ref = MarginalReference(sde, "gmm", means_init=means, variances_init=0.5 * torch.ones(K, d), weights_init=torch.ones(K))
-    for m in (sde, target, ctrl, ref):
-        m.to(device)
-    loss = EIReferenceSDELoss(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref)
-    ts = get_timesteps(0.0, 1.0, steps=N).to(device)
-    gen = torch.Generator().manual_seed(seed)
-    x0 = torch.randn(B, d, generator=gen).to(device)
-    args = (target.unnorm_log_prob, ref.reference_distr.to(device).log_prob)
-    parts = dict(sde=sde, target=target, ctrl=ctrl, means=means, K=K, d=d)
-    flops = 2 * (2 * 64 * d + 2 * 64 * 64)  # drift-net MACs*2 per particle-step: 49 152 at d=128
-    return loss, ts, x0, args, parts, flops
 
 
 def host_cores() -> int:
@@ -142,7 +112,9 @@ def main():
     from sde_sampler_lrds_amd import _lib as L
     from sde_sampler_lrds_amd import parallel
     B, N = a.particles, a.sde_steps
-    loss, ts, x0, args, parts, flops_ps = build_rds_gmm(device, B, N, K=a.modes, seed=1 + rank)
+    from sde_sampler_lrds_amd.experiments.baseline_configs import build_rds_gmm
+    loss, ts, x0, args, _, parts = build_rds_gmm(device, B, N, K=a.modes, seed=1 + rank)
+    flops_ps = parts["flops"]
     loss.seed = 1
     loss.particle0 = rank * B  # global particle index -> sharding-independent noise
     ev = L.HipEvents()

@@ -23,7 +23,14 @@ LIB = os.path.join(PKG, "libsdeng.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the integrator and log-weight updates must round like the reference's separate
 # torch ops (no silent a*b+c fusion); fused multiply-adds are written explicitly where wanted.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wno-comment"]
+# -packed-fp32-ops: no v_pk_{add,mul,fma}_f32.  With two waves per SIMD the -O3 build that used them produced
+# rare corrupt values (one 16-lane row, low half of a register pair) in the mixture-score phase: ~20 % of the
+# tiles of a 65 536 x 64 run differed between reruns, none with one wave per SIMD, -O1, -fno-slp-vectorize or this
+# flag (tools/probe_determinism.py, tools/probe_divergence.py; not reproduced in isolation by
+# tools/ubench/mfma_pk_hazard.hip).  Packed fp32 buys ~12 % per element at best on this part
+# (profiles/r01_ubench_valu_cost.log), so nothing is lost.  tests/test_gpu_fullsize.py guards rerun equality.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-command-line-argument",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 if os.environ.get("SDENG_DEFS"):  # experiment knob: extra -D flags (ablation builds)
     FLAGS += ["-D" + d for d in os.environ["SDENG_DEFS"].split()]
 if os.environ.get("SDENG_WAVES"):  # experiment knob: waves per workgroup (8 = 2 per SIMD, 4 = 1 per SIMD)

@@ -224,14 +224,27 @@ SD_INLINE void mlp_out_tiles(const f32x4 (&a)[SD_HT], const float* lds, const fl
 // step k+1 is issued once the wave has read step k's table for the last time and lands under the next step's
 // MFMA phase; the reader waits with s_waitcnt vmcnt(0) (nothing else orders a ds_read behind an LDS-DMA).
 // ----------------------------------------------------------------------------------------------
+// Every chunk uses the SAME M0 (the wave's slot base) and advances through the instruction's immediate offset,
+// which applies to the global and the LDS address alike.  Rewriting M0 between the chunks (one s_add m0 per
+// 1 KiB) is not safe on gfx950: under load the queued LDS-DMA of chunk i picked up the M0 written for chunk
+// i+1 and landed 1 KiB off -- silently wrong tables in ~20 % of the tiles at full occupancy, none in a small
+// launch (tools/probe_determinism.py, tests/test_gpu_fullsize.py).
 SD_INLINE void dma_table_to_lds(const float* __restrict__ gsrc, float* lds_dst, int n_floats, int lane) {
-  for (int c = 0; c * 256 < n_floats; ++c) {  // 1 KiB per wave-instruction
-    typedef __attribute__((address_space(1))) void gvoid;
-    typedef __attribute__((address_space(3))) void lvoid;
-    __builtin_amdgcn_global_load_lds((gvoid*)(gsrc + c * 256 + lane * 4), (lvoid*)(lds_dst + c * 256), 16, 0, 0);
-  }
+  typedef __attribute__((address_space(1))) void gvoid;
+  typedef __attribute__((address_space(3))) void lvoid;
+  gvoid* g = (gvoid*)(gsrc + lane * 4);
+  lvoid* l = (lvoid*)lds_dst;
+  __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);  // 1 KiB per wave-instruction
+  if (n_floats > 256) __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+  if (n_floats > 512) __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+  if (n_floats > 768) __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+  static_assert(SD_REFTAB_FLOATS <= 1024, "four 1 KiB chunks");
 }
+#ifdef SD_DBG_WAITMORE
+SD_INLINE void wait_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_sleep 8\n\ts_nop 7" ::: "memory"); }
+#else
 SD_INLINE void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // counter-based noise: Philox4x32-10 + Box-Muller (definition shared with oracle.philox_normal)

@@ -49,7 +49,11 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   __syncthreads();
   const float* bias = a.wpack + sd_off_bias(NT);
   // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)
+#ifdef SD_DBG_NODMA
+  constexpr bool ref_lds = false;
+#else
   constexpr bool ref_lds = (REF == RF_GAUSS || REF == RF_GMM);
+#endif
   float* my_tab = lds + sd_lds_weight_floats(NT) + wave * SD_REFTAB_FLOATS;
   const int tab_floats = a.ref_k * 2 * dpad;
   const int p = lane & 15, g = lane >> 4;

@@ -1,0 +1,118 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties:
+
+* sharding independence: the batch simulated as two shards (Philox keyed by global particle index) equals the
+  single-shard run BIT FOR BIT, and a rerun is bit-identical (no atomics, no order dependence);
+* a block of 32 particles from the middle of the batch equals the CPU oracle run on just those particles with the
+  same counter-based noise (Philox mode; tolerance as tests/test_gpu_parity.py: hardware sin/cos/log2 vs libm);
+* estimator identities: log Z / ELBO / ESS from the HIP reduction equal fp64 torch on the same log-weights, the
+  softmax weights sum to one.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import sde_oracle as orc
+from sde_sampler_lrds_amd import engine as E
+from sde_sampler_lrds_amd import parallel
+from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
+from tests import golden_cases as gc
+
+P0, PB = 40000, 32  # the block of particles cross-checked against the oracle
+
+
+def _sd(mod):
+    return {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+
+
+def _run_full_and_shards(loss, ts, x0, args, kw):
+    B = x0.shape[0]
+    cut = (B // 2) + 16 * 3 + 5  # a cut that is not a multiple of the 16-particle tile
+    loss.particle0 = 0
+    full = loss.simulate(ts, x0, *args, **kw)
+    for _ in range(3):  # reruns at full occupancy: every wave, every step must reproduce (this caught a hardware-level
+        again = loss.simulate(ts, x0, *args, **kw)  # corruption that no small-batch test could see)
+        assert torch.equal(full[0], again[0]) and torch.equal(full[1], again[1]), "rerun differs"
+    a = loss.simulate(ts, x0[:cut], *args, **kw)
+    loss.particle0 = cut
+    z = loss.simulate(ts, x0[cut:].contiguous(), *args, **kw)
+    loss.particle0 = 0
+    assert torch.equal(torch.cat([a[0], z[0]]), full[0]), "x_N depends on the sharding"
+    assert torch.equal(torch.cat([a[1], z[1]]), full[1]), "log-weights depend on the sharding"
+    assert bool(torch.isfinite(full[0]).all()) and bool(torch.isfinite(full[1]).all())
+    return full
+
+
+def _check_estimators(rnd):
+    res = parallel.global_results(rnd)
+    r = (-rnd.double().flatten()).cpu()
+    logz = float(torch.logsumexp(r, 0) - math.log(r.numel()))
+    w = torch.softmax(r, 0)
+    assert abs(res["log_norm_const_is"] - logz) < 1e-4 * max(1.0, abs(logz))
+    assert abs(res["elbo"] - float(r.mean())) < 1e-4 * max(1.0, abs(float(r.mean())))
+    assert abs(res["ess"] - float(1.0 / (w * w).sum() / r.numel())) < 1e-4
+    _, weights = E.logz_stats(rnd, want_weights=True)
+    assert abs(float(weights.double().sum()) - 1.0) < 1e-4
+
+
+def _tol(x_err, rnd_err, name):
+    print(f"{name}: block [{P0},{P0 + PB}) vs oracle: x_N {x_err:.2e}, rnd {rnd_err:.2e}")
+    assert x_err < 2e-4 and rnd_err < 2e-4
+
+
+def _rnd_err(rnd, ref, scale):
+    return float((rnd.cpu().flatten() - ref.flatten()).abs().max()) / scale
+
+
+@pytest.mark.gpu
+def test_cfg2_rds_gmm_65536x256(gpu):
+    B, N = 65536, 256
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N)
+    loss.seed = 5
+    x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
+    _check_estimators(rnd)
+    sde = orc.VP(0.1, 10.0, 1.0, 1.0)
+    tgt = orc.GMMDiag(info["target"].loc.cpu(), info["target"].scale.cpu(), info["target"].mixture_weights.cpu())
+    ctrl = orc.Ctrl(_sd(info["ctrl"]), "clipped", clip_model=1e4)
+    means, var, w = info["means"].cpu(), 0.5 * torch.ones(info["K"], info["d"]), torch.ones(info["K"])
+    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+    refd = orc.GMMDiag(loc0, v0.sqrt(), w)
+    with torch.no_grad():
+        ox, ornd, _ = orc.simulate_ei_ref(ts.cpu(), x0[P0:P0 + PB].cpu(), ctrl, sde, tgt.logp, refd.logp,
+                                          lambda t, xx: orc.mog_score(xx, w, *sde.marginal_diag(t, means, var)),
+                                          orc.PhiloxNoise(5, particle0=P0))
+    _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(tgt.logp(ox).abs().max()))), "cfg2")
+
+
+@pytest.mark.gpu
+def test_cfg3_pis_phi4_131072x512(gpu):
+    B, N = 131072, 512
+    loss, ts, x0, args, kw, info = cfgs.build_pis_phi4(gpu, B, N)
+    loss.seed = 6
+    x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
+    _check_estimators(rnd)
+    g, T = math.sqrt(0.2), 5.0
+    sde = orc.ScaledBM(g, T)
+    tgt = orc.PhiFour(0.1, 0.0, info["d"], 20.0)
+    ctrl = orc.Ctrl(_sd(info["ctrl"]), "score", clip_model=1e4, target_score=tgt.score, clip_score=1e4, scale_score=1.0)
+    refd = orc.GaussDiag(torch.zeros(info["d"]), torch.full((info["d"],), g * math.sqrt(T)))
+    with torch.no_grad():
+        ox, ornd, _ = orc.simulate_em_ref(ts.cpu(), x0[P0:P0 + PB].cpu(), ctrl, sde, tgt.logp, refd.logp, None,
+                                          orc.PhiloxNoise(6, particle0=P0))
+    _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(ornd.abs().max()))), "cfg3")
+
+
+@pytest.mark.gpu
+def test_cfg4_cmcd_logreg_shard_65536x256(gpu):
+    B, N = 65536, 256
+    loss, ts, x0, args, kw, info = cfgs.build_cmcd_logreg(gpu, B, N)
+    loss.seed = 7
+    x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
+    _check_estimators(rnd)
+    tgt = orc.LogReg(info["X"], info["y"], 4.5, -2.5, 0.5)
+    prior = orc.GaussFull(info["mean"], info["cov"])
+    ctrl = orc.Ctrl(_sd(info["ctrl"]), "score", clip_model=1e4, target_score=tgt.score, clip_score=1e4, scale_score=1.0)
+    with torch.no_grad():
+        ox, ornd, _ = orc.simulate_cmcd(ts.cpu(), x0[P0:P0 + PB].cpu(), ctrl, tgt.score, prior.score, 1.0, 1.0, 1e5, tgt.logp,
+                                        prior.logp, orc.PhiloxNoise(7, particle0=P0))
+    _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(ornd.abs().max()))), "cfg4")

@@ -13,7 +13,8 @@ from sde_sampler_lrds_amd import _lib as L
 if os.environ.get("SDENG_LIB"): L.LIB_PATH = os.environ["SDENG_LIB"]
 import bench
 dev = torch.device("cuda:0")
-loss, ts, x0, args, parts, fl = bench.build_rds_gmm(dev, 65536, 256, K=4)
+loss, ts, x0, args, _, info = build_rds_gmm(dev, 65536, 256, K=4)
+fl = info["flops"]
 ev = L.HipEvents(); loss.timing_events = ev
 best = 1e9
 for rep in range(4):

@@ -11,11 +11,12 @@ from sde_sampler_lrds_amd import _lib as L  # noqa: E402
 
 if alt:
     L.LIB_PATH = alt
-import bench  # noqa: E402
+from sde_sampler_lrds_amd.experiments.baseline_configs import build_rds_gmm  # noqa: E402
 
 dev = torch.device("cuda:0")
 for (B, N, K) in [(2048, 100, 4), (65536, 64, 4), (65536, 256, 4), (131072, 256, 4), (65536, 256, 16)]:
-    loss, ts, x0, args, parts, fl = bench.build_rds_gmm(dev, B, N, K=K)
+    loss, ts, x0, args, _, info = build_rds_gmm(dev, B, N, K=K)
+    fl = info["flops"]
     ev = L.HipEvents()
     loss.timing_events = ev
     for rep in range(3):
