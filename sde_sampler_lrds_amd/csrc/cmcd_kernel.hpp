@@ -128,11 +128,12 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   // ---- control ----
   f32x4 hid[SD_HT];
   mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane);
+  const HidSplit hs = split_hidden(hid);
   const float st = s.stheta ? s.stheta[ki] : 1.0f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     f32x4 o[1];
-    mlp_out_tiles<NT, 1>(hid, lds, bias, t, lane, o);
+    mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, o);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float uv = o[0][r];

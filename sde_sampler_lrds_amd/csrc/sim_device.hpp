@@ -49,14 +49,29 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define SD_LO_SCALE 2048.0f
 #define SD_LO_INV 4.8828125e-04f
 
+// One pair of values -> packed (hi, lo) halves in 6 instructions: v_cvt_pk_f16_f32 (round to nearest even), two
+// v_fma_mix_f32 that subtract the f16 halves from the fp32 values exactly (v*1.0 - hi with the f16 operand read in
+// place: no separate f16->f32 conversion), two scalings, one v_cvt_pk_f16_f32.  hipcc's own lowering of the same
+// expression takes 11 (it converts every half twice).  Plain asm, no side effects: the compiler may schedule and
+// merge these statements freely.
+SD_INLINE void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  float d0, d1;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(a), "v"(hi));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(b), "v"(hi));
+  d0 *= SD_LO_SCALE;
+  d1 *= SD_LO_SCALE;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 SD_INLINE void split8(const f32x4& t0, const f32x4& t1, f16x8& hi, f16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = j < 4 ? t0[j & 3] : t1[j & 3];
-    const _Float16 h = static_cast<_Float16>(v);
-    hi[j] = h;
-    lo[j] = static_cast<_Float16>((v - static_cast<float>(h)) * SD_LO_SCALE);
-  }
+  uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+  split_pair(t0[0], t0[1], h0, l0);
+  split_pair(t0[2], t0[3], h1, l1);
+  split_pair(t1[0], t1[1], h2, l2);
+  split_pair(t1[2], t1[3], h3, l3);
+  hi = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
+  lo = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
 }
 
 // one layer: out[to] = bias[to] (preloaded in `out`) + W in.  The activations are split K-block by K-block right
@@ -211,12 +226,26 @@ SD_INLINE void mlp_hidden_pre(const f16x8 (&xh)[(NT + 1) / 2], const f16x8 (&xl)
   gelu_tiles<SD_HT>(a);
 }
 
+// the last hidden activation, split once per step for all output tiles
+struct HidSplit {
+  f16x8 h[2], l[2];
+};
+SD_INLINE HidSplit split_hidden(const f32x4 (&a)[SD_HT]) {
+  HidSplit s;
+  split_tiles<SD_HT>(a, s.h, s.l);
+  return s;
+}
 template <int NT, int OT>
-SD_INLINE void mlp_out_tiles(const f32x4 (&a)[SD_HT], const float* lds, const float* bias, int t0, int lane, f32x4 (&u)[OT]) {
+SD_INLINE void mlp_out_tiles(const HidSplit& hs, const float* lds, const float* bias, int t0, int lane, f32x4 (&u)[OT]) {
   const int g = lane >> 4;
+  f32x4 mx[OT];
 #pragma unroll
-  for (int o = 0; o < OT; ++o) u[o] = load_tile4(bias + 192, t0 + o, g);  // b_out
-  dense<SD_HT, OT>(a, u, lds + sd_off_wout(NT) + t0 * 2 * 512, lane);
+  for (int o = 0; o < OT; ++o) {
+    u[o] = load_tile4(bias + 192, t0 + o, g);  // b_out
+    mx[o] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  dense_pre<2, OT>(hs.h, hs.l, u, mx, reinterpret_cast<const f16x8*>(lds + sd_off_wout(NT) + t0 * 2 * 512), lane);
+  fold_lo<OT>(u, mx);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       // ---- drift net up to the last hidden activation (FP32 MFMA chain) ----
       f32x4 hid[SD_HT];
       mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
+      const HidSplit hs = split_hidden(hid);
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
       f32x4 ts[SC != SC_NONE ? NT : 1];
@@ -118,14 +119,28 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 #pragma unroll
       for (int t0 = 0; t0 < NT; t0 += OT) {
         f32x4 u[OT];
-        mlp_out_tiles<NT, OT>(hid, lds, bias, t0, lane, u);
+        mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
+        if (a.clip_model > 0.0f) {
+          // ClippedCtrl's clip (reparam.py:42) almost never binds (clip_model = 1e4): one compare per element into a
+          // wave-wide mask, and the 4-instruction NaN-preserving clamp only when some lane is out of range or NaN
+          bool out_of_range = false;
+#pragma unroll
+          for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out_of_range |= !(__builtin_fabsf(u[o][r]) <= a.clip_model);
+          if (__builtin_amdgcn_ballot_w64(out_of_range) != 0) {
+#pragma unroll
+            for (int o = 0; o < OT; ++o)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) u[o][r] = clampf(u[o][r], a.clip_model);
+          }
+        }
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
           const int t = t0 + o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float uv = u[o][r];
-            if (a.clip_model > 0.0f) uv = clampf(uv, a.clip_model);
             if constexpr (SC != SC_NONE)
               uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * g, d_dyn));
             u[o][r] = uv;
@@ -222,6 +237,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
     const float score_gain = a.coef[7], lerp_w = a.coef[8];
     f32x4 hid[SD_HT];
     mlp_hidden<NT>(x, hid, lds, bias, a.temb, lane);
+    const HidSplit hs = split_hidden(hid);
     f32x4 ts[SC != SC_NONE ? NT : 1];
     if constexpr (SC == SC_GMM) {
       if (NT == 1 && a.target.kind == SDENG_DIST_RINGS) ts[0] = rings_score(x[0], a.target, g);
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4 u[1];
-      mlp_out_tiles<NT, 1>(hid, lds, bias, t, lane, u);
+      mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, u);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float uv = u[0][r];

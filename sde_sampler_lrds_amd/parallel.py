@@ -42,16 +42,32 @@ def combine_stats(stats: torch.Tensor, counts: torch.Tensor) -> dict:
     }
 
 
-def global_results(rnd: torch.Tensor, dist=None) -> dict:
-    """Estimators over ALL ranks' particles from this rank's ``rnd`` shard [B,1] (device tensor)."""
+class PendingResults:
+    """Estimators of one pass, still on the device: every kernel (and the all-gather) is enqueued, nothing has been
+    read back.  ``result()`` synchronises and combines on the host.  Lets a caller keep several passes in flight."""
+
+    def __init__(self, gathered: torch.Tensor):
+        self.gathered = gathered  # [W, 9]: sdeng_logz statistics + particle count per rank
+
+    def result(self) -> dict:
+        g = self.gathered
+        return combine_stats(g[:, :8], g[:, 8])
+
+
+def global_results_async(rnd: torch.Tensor, dist=None) -> PendingResults:
+    """Enqueue the estimators over ALL ranks' particles from this rank's ``rnd`` shard [B,1] (device tensor)."""
     from . import engine
     stats, _ = engine.logz_stats(rnd, want_weights=False)
     count = torch.tensor([float(rnd.shape[0])], device=rnd.device)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return combine_stats(stats.view(1, 8), count)
-    world = dist.get_world_size()
     payload = torch.cat([stats, count])
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return PendingResults(payload.view(1, 9))
+    world = dist.get_world_size()
     gathered = torch.empty(world * 9, dtype=payload.dtype, device=payload.device)
     dist.all_gather_into_tensor(gathered, payload)
-    gathered = gathered.view(world, 9)
-    return combine_stats(gathered[:, :8], gathered[:, 8])
+    return PendingResults(gathered.view(world, 9))
+
+
+def global_results(rnd: torch.Tensor, dist=None) -> dict:
+    """Estimators over ALL ranks' particles from this rank's ``rnd`` shard [B,1] (device tensor)."""
+    return global_results_async(rnd, dist).result()
