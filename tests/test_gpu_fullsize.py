@@ -116,3 +116,39 @@ def test_cfg4_cmcd_logreg_shard_65536x256(gpu):
         ox, ornd, _ = orc.simulate_cmcd(ts.cpu(), x0[P0:P0 + PB].cpu(), ctrl, tgt.score, prior.score, 1.0, 1.0, 1e5, tgt.logp,
                                         prior.logp, orc.PhiloxNoise(7, particle0=P0))
     _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(ornd.abs().max()))), "cfg4")
+
+
+# ---- every kernel family at full occupancy --------------------------------------------------------------------------
+# The golden cases replicated to 32 768+ particles (each replica draws its own Philox noise): reruns and shards must be
+# bit-identical, and blocks of the big run -- chosen so that every wave slot of a workgroup is covered -- must equal a
+# small launch of just that block (one wave per SIMD: the regime the fixtures pin against the reference).
+BIG = [("rds_ei_gmm_d128_k16", 32768), ("rds_ei_gmm_d8_k4", 65536), ("rds_ddpm_gmm_d16_snr", 65536), ("rds_em_gmm_d16", 65536),
+       ("rds_ei_vp_default_d16", 65536), ("rds_ei_pbm_default_d16", 65536), ("dds_two_modes_d2", 65536), ("dds_rings_d2", 65536),
+       ("dis_ei_d8", 65536), ("dis_orig_lerp_d8", 65536), ("pis_em_phi4_d100", 32768), ("cmcd_logreg_d61", 32768)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B", BIG)
+def test_every_kernel_family_at_full_occupancy(gpu, name, B):
+    from tests import build_cases as bc
+    c = gc.load(name)
+    b = bc.build(c, gpu)
+    loss, ts, args, kw = b["loss"], b["ts"], b["args"], b["kwargs"]
+    x0 = b["x0"].repeat((B + b["x0"].shape[0] - 1) // b["x0"].shape[0], 1)[:B].contiguous()
+    loss.particle0 = 0
+    full = loss.simulate(ts, x0, *args, **kw)
+    for _ in range(2):
+        again = loss.simulate(ts, x0, *args, **kw)
+        assert torch.equal(full[0], again[0]) and torch.equal(full[1], again[1]), "rerun differs"
+    ntiles, grid = B // 16, min(256, B // 16)
+    for wave in range(8):  # tile = block + grid * (wave + 8 * round): one block per wave slot
+        tile = 37 + grid * wave
+        if tile >= ntiles:
+            break
+        lo = 16 * tile - 8  # straddles a tile boundary on purpose
+        loss.particle0 = lo
+        part = loss.simulate(ts, x0[lo:lo + 48].contiguous(), *args, **kw)
+        assert torch.equal(part[0], full[0][lo:lo + 48]), f"wave slot {wave}: x_N of the block differs from the full launch"
+        assert torch.equal(part[1], full[1][lo:lo + 48]), f"wave slot {wave}: log-weights of the block differ"
+    loss.particle0 = 0
+    assert bool(torch.isfinite(full[1]).all())
