@@ -45,10 +45,17 @@ extern "C" {
  *                  EMReferenceSDELoss.simulate        losses/oc.py:218-296  (PIS: no reference)
  *                  TimeReversalLoss.simulate          losses/oc.py:1133-1238 (no inference control)
  * SDENG_FORM_CMCD  ControlledLangevinSDELoss.simulate losses/oc.py:666-755 (+ eq/sdes.py:101-110)
+ * SDENG_FORM_EUBO  the noising loops (x_in = samples of the target; coef rows in ITERATION order, i.e. times T - s run backwards):
+ *                  x' = x*c1 + c3*z ; u = c2*ctrl(t_net, x') ; rnd -= c4*<u, ref(x') + u/2> ; rnd += c6*<u, x'> ; rnd -= c5*<u, z>
+ *                  EIReferenceSDELoss.compute_eubo    losses/oc.py:512-568  (c2 = 1, c6 = 0)
+ *                  EMReferenceSDELoss.compute_eubo    losses/oc.py:298-362  (also DDPMLikeReferenceSDELoss)
+ *                  FLAG_TERM_REF / FLAG_TERM_TARGET here mean the INITIAL cost rnd0 = log p_ref(x_in) - log pi~(x_in) (:322, :536);
+ *                  needs a reference (ref.kind != NONE) and a ClippedCtrl.
  */
 #define SDENG_FORM_LIN 0
 #define SDENG_FORM_EM 1
 #define SDENG_FORM_CMCD 2
+#define SDENG_FORM_EUBO 3
 
 /* Per-step coefficient table: coef[N][SDENG_NCOEF], filled by the host with the reference's own
  * fp32 scalar formulas (eq/sdes.py:456-555, 609-678; losses/oc.py:1369-1371).  Column meaning:

@@ -701,6 +701,51 @@ def simulate_ei_ref(ts, x, ctrl, sde, terminal_logp, ref_logp, ref_score, noise=
     return x, rnd, (torch.stack(xs) if return_traj else None)
 
 
+def eubo_ei_ref(ts, x, ctrl, sde, terminal_logp, ref_logp, ref_score, noise=None):
+    """losses/oc.py:512-568 EIReferenceSDELoss.compute_eubo: noising trajectories from target samples x."""
+    noise = noise or TorchNoise()
+    rnd = ref_logp(x).view((-1, 1)) - terminal_logp(x)
+    T = ts[-1]
+    times_s, times_t = ts[:-1].flip((0,)), ts[1:].flip((0,))
+    mean_f, var_f = sde.transition_params(T - times_t, T - times_s)
+    std_f = var_f.sqrt()
+    for i, (s, t) in enumerate(zip(times_s, times_t)):
+        z = noise(i, x)
+        x = x * mean_f[i]
+        x = x + std_f[i] * z
+        u = ctrl(T - s, x)
+        r = ref_score(T - s, x)
+        cost = u * (r + 0.5 * u)
+        rnd = rnd - cost.sum(dim=-1, keepdim=True) * sde.omega(s, t)
+        rnd = rnd - (u * z).sum(dim=-1, keepdim=True) * torch.sqrt(sde.omega(s, t))
+    return x, rnd
+
+
+def eubo_em_ref(ts, x, ctrl, sde, terminal_logp, ref_logp, ref_score, noise=None, use_rescaling=True):
+    """losses/oc.py:298-362 EMReferenceSDELoss.compute_eubo (also DDPMLikeReferenceSDELoss, which inherits it)."""
+    noise = noise or TorchNoise()
+    rnd = ref_logp(x).view((-1, 1)) - terminal_logp(x)
+    T = ts[-1]
+    times_s, times_t = ts[:-1].flip((0,)), ts[1:].flip((0,))
+    mean_f, var_f = sde.transition_params(T - times_t, T - times_s)
+    std_f = var_f.sqrt()
+    for i, (s, t) in enumerate(zip(times_s, times_t)):
+        z = noise(i, x)
+        x = x * mean_f[i]
+        x = x + std_f[i] * z
+        u = ctrl(T - s, x)
+        r = ref_score(T - s, x)
+        g = sde.diff(T - s)
+        dt = t - s
+        if use_rescaling:
+            u = u / g
+        cost = u * (r + 0.5 * u)
+        rnd = rnd - cost.sum(dim=-1, keepdim=True) * dt * g ** 2
+        rnd = rnd + (u * x).sum(dim=-1, keepdim=True) * (1.0 / mean_f[i] - 1.0 + sde.drift_coeff(T - s) * dt)
+        rnd = rnd - (u * z).sum(dim=-1, keepdim=True) * (std_f[i] / mean_f[i])
+    return x, rnd
+
+
 def simulate_dis_ei(ts, x, ctrl, sde, terminal_logp, initial_logp, noise=None, return_traj=False):
     """losses/oc.py:906-978 DiscreteTimeReversalLossEI.simulate (eval: rnd0 = prior log-prob)."""
     noise = noise or TorchNoise()

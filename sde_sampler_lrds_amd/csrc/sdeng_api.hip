@@ -32,6 +32,11 @@ SD_FOR_REF(SD_DECLARE_SIM, 1)
 SD_FOR_REF(SD_DECLARE_SIM, 2)
 SD_FOR_REF(SD_DECLARE_SIM, 4)
 SD_FOR_REF(SD_DECLARE_SIM, 8)
+#define SD_EUBO_ROW(M, DT) M(DT, 1, 0, 3) M(DT, 2, 0, 3) M(DT, 3, 0, 3)
+SD_EUBO_ROW(SD_DECLARE_SIM, 1)
+SD_EUBO_ROW(SD_DECLARE_SIM, 2)
+SD_EUBO_ROW(SD_DECLARE_SIM, 4)
+SD_EUBO_ROW(SD_DECLARE_SIM, 8)
 #define SD_CTRL_ROW(M, DT) M(DT, 0) M(DT, 1) M(DT, 2)
 SD_CTRL_ROW(SD_DECLARE_CTRL, 1)
 SD_CTRL_ROW(SD_DECLARE_CTRL, 2)
@@ -44,6 +49,8 @@ static const sim_launch_fn kSimTable[4][4][3][2] = {
 #define SD_TAB_SC(DT, REF) {SD_TAB_FORM(DT, REF, 0) SD_TAB_FORM(DT, REF, 1) SD_TAB_FORM(DT, REF, 2)},
 #define SD_TAB_REF(DT) {SD_TAB_SC(DT, 0) SD_TAB_SC(DT, 1) SD_TAB_SC(DT, 2) SD_TAB_SC(DT, 3)},
     SD_TAB_REF(1) SD_TAB_REF(2) SD_TAB_REF(4) SD_TAB_REF(8)};
+// compute_eubo kernels exist for the reference-SDE losses only: [tiles][reference kind - 1]
+static const sim_launch_fn kEuboTable[4][3] = {{SD_EUBO_ROW(SD_ENTRY, 1)}, {SD_EUBO_ROW(SD_ENTRY, 2)}, {SD_EUBO_ROW(SD_ENTRY, 4)}, {SD_EUBO_ROW(SD_ENTRY, 8)}};
 #define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
 static const sim_launch_fn kCtrlTable[4][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}, {SD_CTRL_ROW(SD_CENTRY, 8)}};
 
@@ -302,7 +309,8 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   if (!d->workspace || d->workspace_bytes < L.total * sizeof(float))
     return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, L.total * sizeof(float));
   if (static_cast<long long>(d->B) * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "B*d >= 2^31");
-  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM && d->form != SDENG_FORM_CMCD) return fail(SDENG_E_INVALID, "unknown form %d", d->form);
+  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM && d->form != SDENG_FORM_CMCD && d->form != SDENG_FORM_EUBO)
+    return fail(SDENG_E_INVALID, "unknown form %d", d->form);
   const int DT = tiles_of(d->d), dpad = 16 * DT;
   float* ws = static_cast<float*>(d->workspace);
 
@@ -364,19 +372,35 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     a.rnd_init = ws + L.rnd_init;
   }
 
-  sim_launch_fn fn = kSimTable[dt_index(DT)][rf][sc][d->form];
+  const bool tr = d->flags & SDENG_FLAG_TERM_REF, tt = d->flags & SDENG_FLAG_TERM_TARGET;
+  if (tr && ref_dist.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_TERM_REF without ref_dist");
+  if (tt && target.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_TERM_TARGET without target");
+  TerminalArgs t;
+  t.ref = ref_dist; t.target = target; t.use_ref = tr; t.use_target = tt;
+  t.B = d->B; t.d = d->d; t.dpad = dpad;
+
+  sim_launch_fn fn;
+  if (d->form == SDENG_FORM_EUBO) {
+    if (rf == RF_NONE) return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels need a reference drift (ref.kind = %d)", d->ref.kind);
+    if (sc != SC_NONE) return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels: ClippedCtrl only");
+    if (d->flags & SDENG_FLAG_INIT_LOGP) return fail(SDENG_E_INVALID, "compute_eubo: FLAG_INIT_LOGP does not apply");
+    fn = kEuboTable[dt_index(DT)][rf - 1];
+    if (tr || tt) {  // cost at the data distribution: rnd0 = log p_ref(x_in) - log pi~(x_in)   (losses/oc.py:322, :536)
+      SD_HIP(hipMemsetAsync(ws + L.rnd_init, 0, sizeof(float) * d->B, s));
+      t.x = d->x_in; t.rnd = ws + L.rnd_init;
+      SD_HIP(sd_launch_terminal(t, s));
+      a.rnd_init = ws + L.rnd_init;
+    }
+  } else {
+    fn = kSimTable[dt_index(DT)][rf][sc][d->form];
+  }
   if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
   SD_HIP(fn(a, grid_for(a.ntiles), s));
   if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
 
   // terminal cost
-  const bool tr = d->flags & SDENG_FLAG_TERM_REF, tt = d->flags & SDENG_FLAG_TERM_TARGET;
-  if (tr || tt) {
-    if (tr && ref_dist.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_TERM_REF without ref_dist");
-    if (tt && target.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_TERM_TARGET without target");
-    TerminalArgs t;
-    t.ref = ref_dist; t.target = target; t.use_ref = tr; t.use_target = tt;
-    t.B = d->B; t.d = d->d; t.dpad = dpad; t.x = d->x_out; t.rnd = d->rnd_out;
+  if (d->form != SDENG_FORM_EUBO && (tr || tt)) {
+    t.x = d->x_out; t.rnd = d->rnd_out;
     SD_HIP(sd_launch_terminal(t, s));
   }
   return 0;

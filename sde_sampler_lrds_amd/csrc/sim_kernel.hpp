@@ -58,6 +58,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   const int tab_floats = a.ref_k * 2 * dpad;
   const int p = lane & 15, g = lane >> 4;
   constexpr bool lin = FORM == SDENG_FORM_LIN;
+  constexpr bool eubo = FORM == SDENG_FORM_EUBO;  // noising direction (compute_eubo)
+  static_assert(!eubo || (SC == SC_NONE && REF != RF_NONE), "EUBO kernels: reference-SDE losses with a ClippedCtrl");
   const bool full_d = a.d == dpad;
   float* trash = a.trash + tid * 4;
 
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       if (a.N > 0) dma_table_to_lds(a.ref_tab, my_tab, tab_floats, lane);
     }
 
-    for (int k = 0; k < a.N; ++k) {
+    for (int k = 0; k < a.N; ++k) {  // EUBO: the host lays the rows out in iteration order (times T - s run backwards)
       const float* cf = a.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5], c6 = cf[6];
       const float score_gain = cf[7], lerp_w = cf[8];
@@ -85,6 +87,28 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       // the step loop, where they would occupy SGPR pairs and spill
       int d_dyn = a.d;
       asm volatile("" : "+s"(d_dyn));
+
+      auto noise_tile = [&](int t) -> f32x4 {
+        if (PAR && a.noise_in) return load_quad(a.noise_in + static_cast<size_t>(k) * a.B * a.d, row, d_dyn, live, t, g);
+        f32x4 z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, a.seed_lo, a.seed_hi);
+        // pad features (f >= d) may carry noise: their weights, table entries and outputs are all zero, so
+        // they never reach a live feature -- except through the phi^4 lattice's neighbour coupling
+        if constexpr (SC == SC_PHI4) {
+          if (!full_d) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = feat_lt(t, r, 4 * g, d_dyn) ? z[r] : 0.0f;
+          }
+        }
+        return z;
+      };
+      if constexpr (eubo) {  // noise the samples first (losses/oc.py:335-337, 549-551): x *= mean_factor; x += std_factor * z
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 z = noise_tile(t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[t][r] = x[t][r] * c1 + c3 * z[r];
+        }
+      }
 
       // ---- drift net up to the last hidden activation (FP32 MFMA chain) ----
       f32x4 hid[SD_HT];
@@ -115,7 +139,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[k] : 1.0f;
 
       // ---- per pair of output tiles: out_layer (MFMA) -> clip -> cost -> noise -> integrator -> Ito term ----
-      float su2 = 0.0f, suz = 0.0f;
+      float su2 = 0.0f, suz = 0.0f, sux = 0.0f;
 #pragma unroll
       for (int t0 = 0; t0 < NT; t0 += OT) {
         f32x4 u[OT];
@@ -143,23 +167,11 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
             float uv = u[o][r];
             if constexpr (SC != SC_NONE)
               uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * g, d_dyn));
+            if constexpr (eubo) uv = uv * c2;  // use_rescaling: generative_ctrl /= sde_diff (losses/oc.py:348-349); 1 for EI
             u[o][r] = uv;
-            su2 = __builtin_fmaf(uv, uv, su2);
+            if constexpr (!eubo) su2 = __builtin_fmaf(uv, uv, su2);
           }
-          f32x4 z;
-          if (PAR && a.noise_in) {
-            z = load_quad(a.noise_in + static_cast<size_t>(k) * a.B * a.d, row, d_dyn, live, t, g);
-          } else {
-            z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, a.seed_lo, a.seed_hi);
-            // pad features (f >= d) may carry noise: their weights, table entries and outputs are all zero, so
-            // they never reach a live feature -- except through the phi^4 lattice's neighbour coupling
-            if constexpr (SC == SC_PHI4) {
-              if (!full_d) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z[r] = feat_lt(t, r, 4 * g, d_dyn) ? z[r] : 0.0f;
-              }
-            }
-          }
+          const f32x4 z = noise_tile(t);  // EUBO: the same counters as in the noising phase above, regenerated
           f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};  // reference score of this tile
 #ifdef SD_DBG_NOREF
           if constexpr (REF == RF_GMM) rq = f32x4{resp[0], resp[0], resp[0], resp[0]};
@@ -171,7 +183,11 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float xv = x[t][r], uv = u[o][r];
-            if constexpr (lin) {  // eq/sdes.py:535-538: ret = c1*x + c2*(ref + u); ret += c3*z
+            if constexpr (eubo) {  // losses/oc.py:352-358, 560-564: running_cost = u (ref + u/2); <u, x>; <u, z>
+              su2 += uv * (rq[r] + 0.5f * uv);
+              sux = __builtin_fmaf(uv, xv, sux);
+              suz = __builtin_fmaf(uv, z[r], suz);
+            } else if constexpr (lin) {  // eq/sdes.py:535-538: ret = c1*x + c2*(ref + u); ret += c3*z
               float sc = uv;
               if constexpr (REF != RF_NONE) sc = rq[r] + uv;
               x[t][r] = (c1 * xv + c2 * sc) + c3 * z[r];
@@ -193,11 +209,17 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       // running cost 0.5*omega*|u|^2 (losses/oc.py:493) or 0.5*|u|^2*dt (:274); per-step constant
       // (TimeReversalLoss: -int drift divergence, :1218-1219); stochastic integral (:284, :499)
       su2 = group_sum(su2);
-      rnd += lin ? c4 * su2 : (0.5f * su2) * c4;
-      rnd += c6;
-      if (a.flags & SDENG_FLAG_ITO) {
-        suz = group_sum(suz);
-        rnd += lin ? c5 * suz : suz;
+      if constexpr (eubo) {  // rnd -= cost * c4;  rnd += <u,x> * c6 (EM only);  rnd -= <u,z> * c5
+        rnd -= su2 * c4;
+        if (c6 != 0.0f) rnd += group_sum(sux) * c6;
+        rnd -= group_sum(suz) * c5;
+      } else {
+        rnd += lin ? c4 * su2 : (0.5f * su2) * c4;
+        rnd += c6;
+        if (a.flags & SDENG_FLAG_ITO) {
+          suz = group_sum(suz);
+          rnd += lin ? c5 * suz : suz;
+        }
       }
       if constexpr (PAR) {
         if (a.xs_out) store_rows<NT>(a.xs_out + static_cast<size_t>(k + 1) * a.B * a.d, trash, row, d_dyn, live, g, x);

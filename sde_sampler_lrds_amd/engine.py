@@ -268,9 +268,9 @@ def _transition_gains(sde, s, t, ddpm):
     raise UnsupportedByEngine(f"{n} has no closed-form EI/DDPM transition kernel")
 
 
-def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, alpha=None, sigma=None, train=False, dim=1) -> torch.Tensor:
+def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, alpha=None, sigma=None, train=False, dim=1, rescale=True) -> torch.Tensor:
     """[N,16] fp32 table (column meaning: include/sdeng.h).  ``kind``: 'ei' | 'ddpm' | 'dis_ei' | 'em' |
-    'time_reversal' | 'dds'.  ``ts`` is a CPU tensor; every entry is produced by the reference's scalar formula."""
+    'time_reversal' | 'dds' | 'eubo_ei' | 'eubo_em'.  ``ts`` is a CPU tensor; every entry is produced by the reference's scalar formula."""
     ts = ts.detach().to("cpu", torch.float32)
     N = ts.numel() - 1
     if kind == "cmcd":  # N+1 rows: row k holds the times/weights of step k; the last row only ts[N] (net time)
@@ -311,6 +311,25 @@ def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, alpha=None, si
             row[4], row[5] = dt, dt.sqrt()
             if not train:
                 row[6] = -(sde.int_drift_coeff_t(s, t) * dim)  # losses/oc.py:1218-1219, eq/sdes.py:137-141
+        elif kind in ("eubo_ei", "eubo_em"):
+            # compute_eubo (losses/oc.py:325-358, 539-564): iteration k noises from time T - t to T - s with
+            # (s, t) = (ts[N-1-k], ts[N-k]); the rows are laid out in iteration order
+            s, t = ts[N - 1 - k], ts[N - k]
+            tau = T - s
+            mean_f, var_f = sde.transition_params(T - t, T - s)
+            std_f = var_f.sqrt()
+            row[0], row[1], row[2], row[3] = tau, mean_f, 1.0, std_f
+            if kind == "eubo_ei":
+                omega = sde.omega(s, t)
+                row[4], row[5] = omega, torch.sqrt(omega)
+            else:
+                g = sde.diff(tau, None)
+                dt = t - s
+                if rescale:
+                    row[2] = 1.0 / g
+                row[4] = dt * g ** 2
+                row[5] = std_f / mean_f
+                row[6] = 1.0 / mean_f - 1.0 + sde.drift_coeff_t(tau) * dt
         elif kind == "dds":
             tau = s
             dt = t - s

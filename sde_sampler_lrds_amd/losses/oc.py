@@ -119,7 +119,8 @@ class BaseOCLoss:
         key = (ts.data_ptr(), ts._version, ts.numel(), str(device), tuple(sorted((k, str(v)) for k, v in kw.items())))
         hit = self._coef_cache.get(key)
         if hit is None:
-            table = E.coef_table(self.kind, ts, self._sde_cpu(), **kw)
+            kw2 = dict(kw)
+            table = E.coef_table(kw2.pop("kind", self.kind), ts, self._sde_cpu(), **kw2)
             hit = table.to(device)
             self._coef_cache = {key: hit}
         return hit
@@ -199,7 +200,7 @@ class BaseOCLoss:
         x_out, rnd, xs = E.run(desc, x, keep, return_traj=return_traj, noise=noise, events=self.timing_events)
         if rnd0 is not None:
             rnd += rnd0
-        rnd = self._apply_late(rnd, x_out, late)
+        rnd = self._apply_late(rnd, x if form == L.FORM_EUBO else x_out, late)  # EUBO: the cost at the data, x_in
         assert rnd.shape == (x.shape[0], 1)
         return x_out, rnd, xs
 
@@ -229,8 +230,19 @@ class EMReferenceSDELoss(BaseOCLoss):
                               form=L.FORM_EM if self.kind == "em" else L.FORM_LIN, flags=L.FLAG_ITO, use_ema=use_ema,
                               return_traj=return_traj, noise=noise, ref=ref, coef_kw=dict(with_ref=ref[0] != "none"))
 
-    def compute_eubo(self, *a, **k):
-        raise E.UnsupportedByEngine("compute_eubo (noising direction) is not on the HIP path yet (SURVEY.md 8f-2)")
+    def compute_eubo(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, use_ema=False, *, noise=None):
+        """losses/oc.py:298-362 (EM; inherited by the DDPM-like loss) and :512-568 (EI): noising trajectories started at
+        target samples ``x`` and the density log-ratio along them, as ONE HIP launch (SDENG_FORM_EUBO).  Like the
+        reference, ``x`` is noised in place."""
+        ref = E.resolve_reference(self.reference_ctrl)
+        if ref[0] == "none":
+            raise E.UnsupportedByEngine("compute_eubo needs a reference control (RDS losses)")
+        kind = "eubo_ei" if self.kind == "ei" else "eubo_em"
+        x_out, rnd, _ = self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
+                                       form=L.FORM_EUBO, flags=0, use_ema=use_ema, return_traj=False, noise=noise, ref=ref,
+                                       coef_kw=dict(with_ref=True, kind=kind, rescale=bool(self.use_rescaling)))
+        x.copy_(x_out)
+        return rnd
 
     def eval(self, ts, x, terminal_unnorm_log_prob, reference_log_prob=None, compute_weights=True, return_traj=True,
              use_ema=True, *, noise=None) -> Results:
@@ -263,8 +275,19 @@ class DDPMLikeReferenceSDELoss(EMReferenceSDELoss):
 class _InitialLogProbLoss(BaseOCLoss):
     """Shared eval() of the losses that start from ``initial_log_prob`` (DIS / CMCD families)."""
 
-    def compute_eubo(self, *a, **k):
-        raise E.UnsupportedByEngine("compute_eubo (noising direction) is not on the HIP path yet (SURVEY.md 8f-2)")
+    def compute_eubo(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, use_ema=False, *, noise=None):
+        """losses/oc.py:298-362 (EM; inherited by the DDPM-like loss) and :512-568 (EI): noising trajectories started at
+        target samples ``x`` and the density log-ratio along them, as ONE HIP launch (SDENG_FORM_EUBO).  Like the
+        reference, ``x`` is noised in place."""
+        ref = E.resolve_reference(self.reference_ctrl)
+        if ref[0] == "none":
+            raise E.UnsupportedByEngine("compute_eubo needs a reference control (RDS losses)")
+        kind = "eubo_ei" if self.kind == "ei" else "eubo_em"
+        x_out, rnd, _ = self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
+                                       form=L.FORM_EUBO, flags=0, use_ema=use_ema, return_traj=False, noise=noise, ref=ref,
+                                       coef_kw=dict(with_ref=True, kind=kind, rescale=bool(self.use_rescaling)))
+        x.copy_(x_out)
+        return rnd
 
     def eval(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, compute_weights=True, return_traj=True,
              use_ema=True, *, noise=None) -> Results:

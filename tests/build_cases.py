@@ -36,6 +36,9 @@ def build(c, device):
     """-> dict(loss, ts, x0, simulate_kwargs) with every module on ``device``."""
     m, kind, d = c.meta, c.meta["kind"], c.meta["d"]
     out = {}
+    if kind == "eubo_gmm":
+        m = dict(m, kind="rds_gmm")
+        kind = "rds_gmm"
     if kind in ("rds_gmm", "rds_default"):
         sde = make_sde(m)
         target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())

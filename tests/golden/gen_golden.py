@@ -175,6 +175,37 @@ def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", b
     finish(name, meta, arrays, res, draws)
 
 
+def case_eubo_gmm(name, d, K, B, N, seed, integrator):
+    """compute_eubo of the RDS losses (losses/oc.py:298-362 EM, :512-568 EI): noising trajectories started at target
+    samples, diagonal-GMM reference, same set-up as case_rds_gmm."""
+    torch.manual_seed(seed)
+    sde = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
+    ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
+    means = target.loc.clone() + 0.1 * torch.randn(K, d)
+    variances, weights = 0.5 * torch.ones(K, d), torch.ones(K)
+
+    def reference_ctrl(t, x):
+        return sde.marginal_gmm_score(t, x, means, variances, weights)
+
+    ref_distr = sde.marginal_gmm_distr(torch.tensor(0.0), means, variances, weights)
+    cls = {"ei": r_oc.EIReferenceSDELoss, "em": r_oc.EMReferenceSDELoss}[integrator]
+    loss = cls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=reference_ctrl)
+    ts = r_get_timesteps(0.0, 1.0, steps=N)
+    # "samples from the target": mode centres + noise, from the engine's counter-based stream (stream 1)
+    comp = torch.arange(B) % K
+    x0 = target.loc[comp] + math.sqrt(0.5) * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    rnd, draws = run_with_replay(seed, lambda: loss.compute_eubo(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob))
+    # compute_eubo noises x in place: rerun on a copy to record the end point
+    xc = x0.clone()
+    run_with_replay(seed, lambda: loss.compute_eubo(ts, xc, target.unnorm_log_prob, ref_distr.log_prob))
+    meta = dict(kind="eubo_gmm", d=d, K=K, B=B, N=N, seed=seed, integrator=integrator, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0,
+                clip_model=1e4, draws=draws)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, out_x=xc, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights,
+                  ref_means=means, ref_vars=variances, ref_w=weights, **pack_params("ctrl.", sd(ctrl)))
+    save(name, meta, arrays)
+
+
 def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em"):
     """RDS with the default Gaussian reference (solver/oc.py:535-551): VP + IsotropicGauss prior, or
     PinnedBM + Delta prior (conf/solver/vp_rds.yaml, pbm_rds.yaml)."""
@@ -466,6 +497,10 @@ CASES = {
     "rds_em_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=64, seed=17, sde_kind="vp", integrator="em"),
     "rds_ei_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=18, sde_kind="vp", integrator="ei"),
     "rds_ei_pbm_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=19, sde_kind="pbm", integrator="ei"),
+    # compute_eubo (noising direction) of the RDS losses
+    "eubo_ei_gmm_d128_k4": lambda n: case_eubo_gmm(n, d=128, K=4, B=64, N=16, seed=61, integrator="ei"),
+    "eubo_ei_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=62, integrator="ei"),
+    "eubo_em_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=63, integrator="em"),
     # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
     "pis_em_phi4_d100": lambda n: case_pis_phi4(n, d=100, B=64, N=32, seed=21, dt=5.0 / 512),
     # config 1 (TwoModes d=2, DDS) and the Rings target on the same solver

@@ -22,6 +22,9 @@ SIM_CASES = [
 ]
 
 
+EUBO_CASES = ["eubo_ei_gmm_d128_k4", "eubo_ei_gmm_d16_k4", "eubo_em_gmm_d16_k4"]  # compute_eubo (noising direction)
+
+
 class Case:
     def __init__(self, name):
         z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
@@ -44,6 +47,21 @@ def make_sde(m):
     if m.get("sde", "vp") == "pbm":
         return orc.PinnedBM(m["diff_coeff"], m["T"])
     return orc.VP(m["beta_min"], m["beta_max"], m["sigma"], m["T"])
+
+
+def run_oracle_eubo(c: Case, noise=None):
+    """Oracle restatement of ``compute_eubo`` for an EUBO case -> (noised x, rnd)."""
+    m = c.meta
+    sde = make_sde(m)
+    tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+    ctrl = orc.Ctrl(c.params("ctrl."), "clipped", clip_model=m["clip_model"])
+    means, var, w = c["ref_means"], c["ref_vars"], c["ref_w"]
+    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+    refd = orc.GMMDiag(loc0, torch.sqrt(v0), w)
+    fn = orc.eubo_ei_ref if m["integrator"] == "ei" else orc.eubo_em_ref
+    with torch.no_grad():
+        return fn(c["ts"], c["x0"], ctrl, sde, tgt.logp, refd.logp, lambda t, x: orc.mog_score(x, w, *sde.marginal_diag(t, means, var)),
+                  noise or orc.PhiloxNoise(m["seed"]))
 
 
 def run_oracle(c: Case, noise=None, B=None):

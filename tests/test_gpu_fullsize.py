@@ -152,3 +152,30 @@ def test_every_kernel_family_at_full_occupancy(gpu, name, B):
         assert torch.equal(part[1], full[1][lo:lo + 48]), f"wave slot {wave}: log-weights of the block differ"
     loss.particle0 = 0
     assert bool(torch.isfinite(full[1]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B", [("eubo_ei_gmm_d128_k4", 32768), ("eubo_em_gmm_d16_k4", 65536)])
+def test_compute_eubo_at_full_occupancy(gpu, name, B):
+    from tests import build_cases as bc
+    c = gc.load(name)
+    b = bc.build(c, gpu)
+    loss, ts, args = b["loss"], b["ts"], b["args"]
+    x0 = b["x0"].repeat((B + b["x0"].shape[0] - 1) // b["x0"].shape[0], 1)[:B].contiguous()
+    loss.particle0 = 0
+    xa = x0.clone()
+    full = loss.compute_eubo(ts, xa, *args)
+    xb = x0.clone()
+    again = loss.compute_eubo(ts, xb, *args)
+    assert torch.equal(full, again) and torch.equal(xa, xb), "rerun differs"
+    for wave in range(8):
+        tile = 37 + min(256, B // 16) * wave
+        if tile >= B // 16:
+            break
+        lo = 16 * tile - 8
+        loss.particle0 = lo
+        xp = x0[lo:lo + 48].clone()
+        part = loss.compute_eubo(ts, xp, *args)
+        assert torch.equal(part, full[lo:lo + 48]) and torch.equal(xp, xa[lo:lo + 48]), f"wave slot {wave}: block differs from the full launch"
+    loss.particle0 = 0
+    assert bool(torch.isfinite(full).all())

@@ -85,6 +85,23 @@ def test_philox_mode_matches_oracle(gpu, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", gc.EUBO_CASES)
+def test_compute_eubo_matches_reference_fixture(gpu, name):
+    """compute_eubo (noising direction, SDENG_FORM_EUBO) against the reference's output: injected noise, then Philox."""
+    c = gc.load(name)
+    b = bc.build(c, gpu)
+    tgt_scale = torch.stack([fn(c["x0"].to(gpu)).view(-1).abs().cpu() for fn in b["args"]] + [c["rnd"].view(-1).abs()]).max(0).values.clamp(min=1.0)
+    for mode, noise, tol in (("injected", replay_noise(c).to(gpu), TOL), ("philox", None, 1e-4)):
+        x = b["x0"].clone()
+        rnd = b["loss"].compute_eubo(b["ts"], x, *b["args"], noise=noise)
+        torch.cuda.synchronize()
+        ex = gc.rel_err(x.cpu(), c["out_x"])  # compute_eubo noises x in place, like the reference
+        ernd = float(((rnd.cpu().view(-1) - c["rnd"].view(-1)).abs() / tgt_scale).max())
+        print(f"{name} [{mode}]: max rel err noised x {ex:.2e}, rnd {ernd:.2e}")
+        assert ex < tol and ernd < tol
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["rds_ei_gmm_d128_k4", "pis_em_phi4_d100", "dds_two_modes_d2"])
 def test_eval_results_match_reference(gpu, name):
     c = gc.load(name)

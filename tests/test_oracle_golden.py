@@ -27,6 +27,15 @@ def test_simulate_matches_reference(name):
     assert gc.rel_err(res["weights"], c["out_weights"]) < 1e-4
 
 
+@pytest.mark.parametrize("name", gc.EUBO_CASES)
+def test_compute_eubo_matches_reference(name):
+    """losses/oc.py:298-362 / :512-568 restated (oracle.eubo_em_ref / eubo_ei_ref) vs the reference's own output."""
+    c = gc.load(name)
+    x, rnd = gc.run_oracle_eubo(c)
+    assert gc.rel_err(x, c["out_x"]) < TOL_SIM
+    assert float((rnd - c["rnd"]).abs().max()) < TOL_SIM * max(1.0, float(c["rnd"].abs().max()))
+
+
 def test_unit_vectors():
     c = gc.load("unit_vectors")
     x = c["gmm_x"]
