@@ -63,6 +63,9 @@ class TrainableDiff:
         self.eval_timesteps = self.train_timesteps
         self.eval_ts = None
         self.use_ema = False
+        # solver/oc.py:37 sets True for every diffusion solver and :356/:436 switch it off for PIS/DDS; here it is on
+        # only where compute_eubo is a HIP launch (the reference-SDE losses of RDS)
+        self.eubo_available = False
         self.seed = cfg.get("seed", 1)
         torch.manual_seed(self.seed)
         self.setup_models()
@@ -218,6 +221,7 @@ class RDS(_ReferenceLogProbSolver):
         super().setup_models()
         self.change_reference_type(ref_type="default")
         self.loss = self.make_loss(reference_ctrl=self.reference_ctrl)
+        self.eubo_available = True
 
     def change_reference_type(self, ref_type="default", net=None, eps=None, mean=None, var=None, means=None,
                               variances=None, weights=None):

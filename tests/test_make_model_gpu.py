@@ -1,4 +1,6 @@
 """The drop-in driver surface: make_model(...) -> solver.evaluate() on the HIP engine (GPU box)."""
+import math
+
 import pytest
 import torch
 
@@ -43,3 +45,22 @@ def test_make_model_variants_run(gpu, solver, ref, integ, mtype, time_type, tnam
     res = model.evaluate()
     assert torch.isfinite(res.samples).all() and torch.isfinite(res.weights).all()
     assert res.samples.shape[0] == 512
+
+
+@pytest.mark.gpu
+def test_trainable_wrapper_evaluate_with_eubo_metrics(gpu):
+    """The notebook flow (additions/hacking.py:36-102): make_model -> TrainableWrapper(model).evaluate(): sampling metrics
+    plus the EUBO-side metrics from noising trajectories started at target samples; both passes on the HIP engine."""
+    from sde_sampler_lrds_amd.additions.hacking import TrainableWrapper
+    tgt = make_target_details("many_modes", dim=16, n_modes=4)
+    K, d = 4, 16
+    g = torch.Generator().manual_seed(0)
+    model = make_model("vp-ref", "gmm", "kl", "ei", "base_zero_init", "uniform",
+                       dict(means_ref=4 * torch.rand(K, d, generator=g) - 2, variances_ref=0.5 * torch.ones(K, d),
+                            weights_ref=torch.ones(K)), tgt, _train(2048), n_steps=32)
+    res = TrainableWrapper(model, verbose=False).evaluate()
+    for key in ("eval/elbo", "eval/eubo", "eval/log_norm_const_is_f", "eval/norm_effective_sample_size_f"):
+        assert key in res.metrics and math.isfinite(res.metrics[key]), key
+    assert 0.0 < res.metrics["eval/norm_effective_sample_size_f"] <= 1.0 + 1e-6
+    # ELBO <= log Z <= EUBO  (log Z = 0 for the normalised mixture target); sampling noise leaves slack
+    assert res.metrics["eval/elbo"] <= res.metrics["eval/eubo"] + 1e-3
