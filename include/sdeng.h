@@ -50,7 +50,9 @@ extern "C" {
  *                  EIReferenceSDELoss.compute_eubo    losses/oc.py:512-568  (c2 = 1, c6 = 0)
  *                  EMReferenceSDELoss.compute_eubo    losses/oc.py:298-362  (also DDPMLikeReferenceSDELoss)
  *                  FLAG_TERM_REF / FLAG_TERM_TARGET here mean the INITIAL cost rnd0 = log p_ref(x_in) - log pi~(x_in) (:322, :536);
- *                  needs a reference (ref.kind != NONE) and a ClippedCtrl.
+ *                  DiscreteTimeReversalLossEI.compute_eubo losses/oc.py:980-1036 (no reference, Score/LerpCtrl, c2 = 1, c6 = 0;
+ *                  FLAG_INIT_LOGP here adds log p_prior of the NOISED samples at the end, :1032)
+ *                  needs either a reference with a ClippedCtrl or no reference with a Score/LerpCtrl.
  */
 #define SDENG_FORM_LIN 0
 #define SDENG_FORM_EM 1

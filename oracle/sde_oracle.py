@@ -746,6 +746,26 @@ def eubo_em_ref(ts, x, ctrl, sde, terminal_logp, ref_logp, ref_score, noise=None
     return x, rnd
 
 
+def eubo_dis_ei(ts, x, ctrl, sde, terminal_logp, initial_logp, noise=None):
+    """losses/oc.py:980-1036 DiscreteTimeReversalLossEI.compute_eubo."""
+    noise = noise or TorchNoise()
+    rnd = -terminal_logp(x)
+    T = ts[-1]
+    times_s, times_t = ts[:-1].flip((0,)), ts[1:].flip((0,))
+    mean_f, var_f = sde.transition_params(T - times_t, T - times_s)
+    std_f = var_f.sqrt()
+    for i, (s, t) in enumerate(zip(times_s, times_t)):
+        z = noise(i, x)
+        x = x * mean_f[i]
+        x = x + std_f[i] * z
+        u = ctrl(T - s, x)
+        cost = 0.5 * u ** 2
+        rnd = rnd - cost.sum(dim=-1, keepdim=True) * sde.omega(s, t)
+        rnd = rnd - (u * z).sum(dim=-1, keepdim=True) * torch.sqrt(sde.omega(s, t))
+    rnd = rnd + initial_logp(x)
+    return x, rnd
+
+
 def simulate_dis_ei(ts, x, ctrl, sde, terminal_logp, initial_logp, noise=None, return_traj=False):
     """losses/oc.py:906-978 DiscreteTimeReversalLossEI.simulate (eval: rnd0 = prior log-prob)."""
     noise = noise or TorchNoise()

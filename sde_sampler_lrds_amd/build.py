@@ -46,7 +46,8 @@ def sources():
         for rf in REFS:
             for sc in SCS:
                 path = os.path.join(GEN, f"sim_{dt}_{rf}_{sc}.hip")
-                forms = FORMS + ((3,) if (sc == 0 and rf > 0) else ())  # 3 = SDENG_FORM_EUBO: reference-SDE losses, ClippedCtrl
+                # 3 = SDENG_FORM_EUBO: reference-SDE losses with a ClippedCtrl, or DIS (score control, no reference)
+                forms = FORMS + ((3,) if ((sc == 0) != (rf == 0)) else ())
                 body = '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, {rf}, {sc}, {fm})\n" for fm in forms)
                 _write_if_changed(path, body)
                 srcs.append(path)

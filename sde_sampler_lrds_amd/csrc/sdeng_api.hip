@@ -32,7 +32,7 @@ SD_FOR_REF(SD_DECLARE_SIM, 1)
 SD_FOR_REF(SD_DECLARE_SIM, 2)
 SD_FOR_REF(SD_DECLARE_SIM, 4)
 SD_FOR_REF(SD_DECLARE_SIM, 8)
-#define SD_EUBO_ROW(M, DT) M(DT, 1, 0, 3) M(DT, 2, 0, 3) M(DT, 3, 0, 3)
+#define SD_EUBO_ROW(M, DT) M(DT, 1, 0, 3) M(DT, 2, 0, 3) M(DT, 3, 0, 3) M(DT, 0, 1, 3) M(DT, 0, 2, 3)
 SD_EUBO_ROW(SD_DECLARE_SIM, 1)
 SD_EUBO_ROW(SD_DECLARE_SIM, 2)
 SD_EUBO_ROW(SD_DECLARE_SIM, 4)
@@ -49,8 +49,9 @@ static const sim_launch_fn kSimTable[4][4][3][2] = {
 #define SD_TAB_SC(DT, REF) {SD_TAB_FORM(DT, REF, 0) SD_TAB_FORM(DT, REF, 1) SD_TAB_FORM(DT, REF, 2)},
 #define SD_TAB_REF(DT) {SD_TAB_SC(DT, 0) SD_TAB_SC(DT, 1) SD_TAB_SC(DT, 2) SD_TAB_SC(DT, 3)},
     SD_TAB_REF(1) SD_TAB_REF(2) SD_TAB_REF(4) SD_TAB_REF(8)};
-// compute_eubo kernels exist for the reference-SDE losses only: [tiles][reference kind - 1]
-static const sim_launch_fn kEuboTable[4][3] = {{SD_EUBO_ROW(SD_ENTRY, 1)}, {SD_EUBO_ROW(SD_ENTRY, 2)}, {SD_EUBO_ROW(SD_ENTRY, 4)}, {SD_EUBO_ROW(SD_ENTRY, 8)}};
+// compute_eubo kernels: [tiles][reference kind - 1] for the reference-SDE losses (ClippedCtrl), [tiles][2 + score kind]
+// for DIS (no reference, ScoreCtrl)
+static const sim_launch_fn kEuboTable[4][5] = {{SD_EUBO_ROW(SD_ENTRY, 1)}, {SD_EUBO_ROW(SD_ENTRY, 2)}, {SD_EUBO_ROW(SD_ENTRY, 4)}, {SD_EUBO_ROW(SD_ENTRY, 8)}};
 #define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
 static const sim_launch_fn kCtrlTable[4][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}, {SD_CTRL_ROW(SD_CENTRY, 8)}};
 
@@ -363,8 +364,8 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   a.target = target;
   a.prior = prior;
 
-  // initial cost
-  if (d->flags & SDENG_FLAG_INIT_LOGP) {
+  // initial cost (EUBO: the prior log-density is added at the END, on the noised samples: losses/oc.py:1032)
+  if ((d->flags & SDENG_FLAG_INIT_LOGP) && d->form != SDENG_FORM_EUBO) {
     if (prior.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_INIT_LOGP without a prior");
     DistEvalArgs e;
     e.ds = prior; e.B = d->B; e.d = d->d; e.dpad = dpad; e.x = d->x_in; e.logp_out = ws + L.rnd_init; e.score_out = nullptr;
@@ -381,11 +382,11 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
 
   sim_launch_fn fn;
   if (d->form == SDENG_FORM_EUBO) {
-    if (rf == RF_NONE) return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels need a reference drift (ref.kind = %d)", d->ref.kind);
-    if (sc != SC_NONE) return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels: ClippedCtrl only");
-    if (d->flags & SDENG_FLAG_INIT_LOGP) return fail(SDENG_E_INVALID, "compute_eubo: FLAG_INIT_LOGP does not apply");
-    fn = kEuboTable[dt_index(DT)][rf - 1];
-    if (tr || tt) {  // cost at the data distribution: rnd0 = log p_ref(x_in) - log pi~(x_in)   (losses/oc.py:322, :536)
+    if ((rf == RF_NONE) == (sc == SC_NONE))
+      return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels: a reference drift with a ClippedCtrl, or no reference with a Score/LerpCtrl "
+                                       "(ref.kind %d, ctrl_kind %d)", d->ref.kind, d->net.ctrl_kind);
+    fn = kEuboTable[dt_index(DT)][rf != RF_NONE ? rf - 1 : 2 + sc];
+    if (tr || tt) {  // cost at the data distribution: rnd0 = [log p_ref(x_in)] - log pi~(x_in)   (losses/oc.py:322, :536, :1003)
       SD_HIP(hipMemsetAsync(ws + L.rnd_init, 0, sizeof(float) * d->B, s));
       t.x = d->x_in; t.rnd = ws + L.rnd_init;
       SD_HIP(sd_launch_terminal(t, s));
@@ -402,6 +403,13 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   if (d->form != SDENG_FORM_EUBO && (tr || tt)) {
     t.x = d->x_out; t.rnd = d->rnd_out;
     SD_HIP(sd_launch_terminal(t, s));
+  }
+  if (d->form == SDENG_FORM_EUBO && (d->flags & SDENG_FLAG_INIT_LOGP)) {  // rnd += log p_prior(x_noised)
+    if (prior.kind == SDENG_DIST_NONE) return fail(SDENG_E_INVALID, "FLAG_INIT_LOGP without a prior");
+    TerminalArgs tp;
+    tp.ref = prior; tp.target = prior; tp.use_ref = 1; tp.use_target = 0;
+    tp.B = d->B; tp.d = d->d; tp.dpad = dpad; tp.x = d->x_out; tp.rnd = d->rnd_out;
+    SD_HIP(sd_launch_terminal(tp, s));
   }
   return 0;
 }

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   const int p = lane & 15, g = lane >> 4;
   constexpr bool lin = FORM == SDENG_FORM_LIN;
   constexpr bool eubo = FORM == SDENG_FORM_EUBO;  // noising direction (compute_eubo)
-  static_assert(!eubo || (SC == SC_NONE && REF != RF_NONE), "EUBO kernels: reference-SDE losses with a ClippedCtrl");
+  static_assert(!eubo || (SC == SC_NONE) != (REF == RF_NONE), "EUBO kernels: reference-SDE losses with a ClippedCtrl, or DIS (no reference)");
   const bool full_d = a.d == dpad;
   float* trash = a.trash + tid * 4;
 

@@ -6,9 +6,10 @@ engine (csrc/) instead of a Python step loop: every step's drift-net forward, sc
 update and log-RND accumulation run inside a single persistent gfx950 kernel.
 
 What is on the HIP path: the eval / sampling direction (``change_sde_ctrl=False``), i.e. what
-``Trainable.evaluate`` times as ``eval/sample_time`` (solver/oc.py:148-158).  The training direction
-(``__call__``: autograd through the net) and ``compute_eubo`` are rows f-1 / f-2 of SURVEY.md section 8 and
-are not built yet: they raise instead of silently running a PyTorch loop.
+``Trainable.evaluate`` times as ``eval/sample_time`` (solver/oc.py:148-158).  ``compute_eubo`` (the noising loops of
+SURVEY.md 8f-2) is a HIP launch too for the RDS losses and DiscreteTimeReversalLossEI.  The training direction
+(``__call__``: autograd through the net, 8f-1) and the CMCD ``compute_eubo`` are not built yet: they raise instead of
+silently running a PyTorch loop.
 
 Extra, engine-only knobs (keyword-only, default to the reference behaviour):
   * ``noise=[N,B,d]`` injects the normals (replays the reference's ``randn_like`` stream, parity mode);
@@ -189,7 +190,7 @@ class BaseOCLoss:
                 desc.prior = E.dist_desc(pr[0], device, keep)
                 desc.flags |= L.FLAG_INIT_LOGP
             except E.UnsupportedByEngine:
-                rnd0 = initial_log_prob(x).view((-1, 1))
+                rnd0 = initial_log_prob if form == L.FORM_EUBO else initial_log_prob(x).view((-1, 1))  # EUBO: at the noised samples
                 if lerp_prior is not None:
                     desc.prior = E.dist_desc(lerp_prior, device, keep)
         elif lerp_prior is not None:
@@ -198,6 +199,8 @@ class BaseOCLoss:
         keep.append(coef)
         desc.coef = coef.data_ptr()
         x_out, rnd, xs = E.run(desc, x, keep, return_traj=return_traj, noise=noise, events=self.timing_events)
+        if callable(rnd0):
+            rnd0 = rnd0(x_out).view((-1, 1))
         if rnd0 is not None:
             rnd += rnd0
         rnd = self._apply_late(rnd, x if form == L.FORM_EUBO else x_out, late)  # EUBO: the cost at the data, x_in
@@ -275,19 +278,9 @@ class DDPMLikeReferenceSDELoss(EMReferenceSDELoss):
 class _InitialLogProbLoss(BaseOCLoss):
     """Shared eval() of the losses that start from ``initial_log_prob`` (DIS / CMCD families)."""
 
-    def compute_eubo(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, use_ema=False, *, noise=None):
-        """losses/oc.py:298-362 (EM; inherited by the DDPM-like loss) and :512-568 (EI): noising trajectories started at
-        target samples ``x`` and the density log-ratio along them, as ONE HIP launch (SDENG_FORM_EUBO).  Like the
-        reference, ``x`` is noised in place."""
-        ref = E.resolve_reference(self.reference_ctrl)
-        if ref[0] == "none":
-            raise E.UnsupportedByEngine("compute_eubo needs a reference control (RDS losses)")
-        kind = "eubo_ei" if self.kind == "ei" else "eubo_em"
-        x_out, rnd, _ = self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
-                                       form=L.FORM_EUBO, flags=0, use_ema=use_ema, return_traj=False, noise=noise, ref=ref,
-                                       coef_kw=dict(with_ref=True, kind=kind, rescale=bool(self.use_rescaling)))
-        x.copy_(x_out)
-        return rnd
+    def compute_eubo(self, *a, **k):
+        raise E.UnsupportedByEngine("compute_eubo of this loss is not on the HIP path yet (SURVEY.md 8f-2); the RDS losses' and "
+                                    "DiscreteTimeReversalLossEI's are")
 
     def eval(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, compute_weights=True, return_traj=True,
              use_ema=True, *, noise=None) -> Results:
@@ -360,6 +353,17 @@ class DiscreteTimeReversalLossEI(_InitialLogProbLoss):
         init = None if (train and self.method in ["kl", "kl_ito"]) else initial_log_prob
         return self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=init,
                               form=L.FORM_LIN, flags=L.FLAG_ITO, use_ema=use_ema, return_traj=return_traj, noise=noise)
+
+    def compute_eubo(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, use_ema=False, *, noise=None):
+        """losses/oc.py:980-1036: noising trajectories from target samples (no reference; cost 0.5|u|^2 omega, Ito term,
+        + log p_prior of the noised samples), one HIP launch.  ``x`` is noised in place like upstream."""
+        if initial_log_prob is None:
+            raise ValueError("compute_eubo needs initial_log_prob (the reference calls it unconditionally, losses/oc.py:1032)")
+        x_out, rnd, _ = self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=initial_log_prob,
+                                       form=L.FORM_EUBO, flags=0, use_ema=use_ema, return_traj=False, noise=noise,
+                                       coef_kw=dict(kind="eubo_ei"))
+        x.copy_(x_out)
+        return rnd
 
 
 class TimeReversalLoss(_InitialLogProbLoss):

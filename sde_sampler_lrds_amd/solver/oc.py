@@ -168,6 +168,7 @@ class Bridge(_InitialLogProbSolver):
         if not isinstance(self.prior, Gauss):
             raise ValueError("Can only be used with Gaussian prior.")
         self.loss = self.make_loss(**({"inference_ctrl": None} if self.cfg["loss"]["kind"] == "TimeReversalLoss" else {}))
+        self.eubo_available = self.cfg["loss"]["kind"] == "DiscreteTimeReversalLossEI"  # the loss whose compute_eubo is a HIP launch
 
 
 class CMCD(_InitialLogProbSolver):

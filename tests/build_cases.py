@@ -39,6 +39,8 @@ def build(c, device):
     if kind == "eubo_gmm":
         m = dict(m, kind="rds_gmm")
         kind = "rds_gmm"
+    if kind == "eubo_dis":
+        kind = "dis_ei"
     if kind in ("rds_gmm", "rds_default"):
         sde = make_sde(m)
         target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())

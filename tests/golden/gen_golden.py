@@ -206,6 +206,27 @@ def case_eubo_gmm(name, d, K, B, N, seed, integrator):
     save(name, meta, arrays)
 
 
+def case_eubo_dis(name, d, K, B, N, seed):
+    """DiscreteTimeReversalLossEI.compute_eubo (losses/oc.py:980-1036), same set-up as case_dis(kind='ei')."""
+    torch.manual_seed(seed)
+    sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=1.0)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.2),
+                           target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
+    loss = r_oc.DiscreteTimeReversalLossEI(ctrl, ctrl, sde=sde, method="kl")
+    ts = r_get_timesteps(0.0, 1.0, steps=N)
+    comp = torch.arange(B) % K
+    x0 = target.loc[comp] + math.sqrt(0.5) * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    xc = x0.clone()
+    rnd, draws = run_with_replay(seed, lambda: loss.compute_eubo(ts, xc, target.unnorm_log_prob, initial_log_prob=prior.log_prob))
+    meta = dict(kind="eubo_dis", d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0, clip_model=1e4,
+                clip_score=1e4, scale_score=1.0, draws=draws)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, out_x=xc, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights,
+                  **pack_params("ctrl.", sd(ctrl)))
+    save(name, meta, arrays)
+
+
 def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em"):
     """RDS with the default Gaussian reference (solver/oc.py:535-551): VP + IsotropicGauss prior, or
     PinnedBM + Delta prior (conf/solver/vp_rds.yaml, pbm_rds.yaml)."""
@@ -501,6 +522,7 @@ CASES = {
     "eubo_ei_gmm_d128_k4": lambda n: case_eubo_gmm(n, d=128, K=4, B=64, N=16, seed=61, integrator="ei"),
     "eubo_ei_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=62, integrator="ei"),
     "eubo_em_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=63, integrator="em"),
+    "eubo_dis_ei_d8": lambda n: case_eubo_dis(n, d=8, K=4, B=64, N=32, seed=64),
     # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
     "pis_em_phi4_d100": lambda n: case_pis_phi4(n, d=100, B=64, N=32, seed=21, dt=5.0 / 512),
     # config 1 (TwoModes d=2, DDS) and the Rings target on the same solver

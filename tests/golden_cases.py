@@ -22,7 +22,7 @@ SIM_CASES = [
 ]
 
 
-EUBO_CASES = ["eubo_ei_gmm_d128_k4", "eubo_ei_gmm_d16_k4", "eubo_em_gmm_d16_k4"]  # compute_eubo (noising direction)
+EUBO_CASES = ["eubo_ei_gmm_d128_k4", "eubo_ei_gmm_d16_k4", "eubo_em_gmm_d16_k4", "eubo_dis_ei_d8"]  # compute_eubo (noising direction)
 
 
 class Case:
@@ -54,6 +54,12 @@ def run_oracle_eubo(c: Case, noise=None):
     m = c.meta
     sde = make_sde(m)
     tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+    if m["kind"] == "eubo_dis":
+        prior = orc.IsoGauss(m["d"], 0.0, 1.0)
+        ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score, clip_score=m["clip_score"],
+                        scale_score=m["scale_score"])
+        with torch.no_grad():
+            return orc.eubo_dis_ei(c["ts"], c["x0"], ctrl, sde, tgt.logp, prior.logp, noise or orc.PhiloxNoise(m["seed"]))
     ctrl = orc.Ctrl(c.params("ctrl."), "clipped", clip_model=m["clip_model"])
     means, var, w = c["ref_means"], c["ref_vars"], c["ref_w"]
     loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)

@@ -155,18 +155,19 @@ def test_every_kernel_family_at_full_occupancy(gpu, name, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,B", [("eubo_ei_gmm_d128_k4", 32768), ("eubo_em_gmm_d16_k4", 65536)])
+@pytest.mark.parametrize("name,B", [("eubo_ei_gmm_d128_k4", 32768), ("eubo_em_gmm_d16_k4", 65536), ("eubo_dis_ei_d8", 65536)])
 def test_compute_eubo_at_full_occupancy(gpu, name, B):
     from tests import build_cases as bc
     c = gc.load(name)
     b = bc.build(c, gpu)
     loss, ts, args = b["loss"], b["ts"], b["args"]
+    kw = {k: v for k, v in b["kwargs"].items() if k == "initial_log_prob"}
     x0 = b["x0"].repeat((B + b["x0"].shape[0] - 1) // b["x0"].shape[0], 1)[:B].contiguous()
     loss.particle0 = 0
     xa = x0.clone()
-    full = loss.compute_eubo(ts, xa, *args)
+    full = loss.compute_eubo(ts, xa, *args, **kw)
     xb = x0.clone()
-    again = loss.compute_eubo(ts, xb, *args)
+    again = loss.compute_eubo(ts, xb, *args, **kw)
     assert torch.equal(full, again) and torch.equal(xa, xb), "rerun differs"
     for wave in range(8):
         tile = 37 + min(256, B // 16) * wave
@@ -175,7 +176,7 @@ def test_compute_eubo_at_full_occupancy(gpu, name, B):
         lo = 16 * tile - 8
         loss.particle0 = lo
         xp = x0[lo:lo + 48].clone()
-        part = loss.compute_eubo(ts, xp, *args)
+        part = loss.compute_eubo(ts, xp, *args, **kw)
         assert torch.equal(part, full[lo:lo + 48]) and torch.equal(xp, xa[lo:lo + 48]), f"wave slot {wave}: block differs from the full launch"
     loss.particle0 = 0
     assert bool(torch.isfinite(full).all())

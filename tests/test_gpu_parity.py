@@ -93,7 +93,8 @@ def test_compute_eubo_matches_reference_fixture(gpu, name):
     tgt_scale = torch.stack([fn(c["x0"].to(gpu)).view(-1).abs().cpu() for fn in b["args"]] + [c["rnd"].view(-1).abs()]).max(0).values.clamp(min=1.0)
     for mode, noise, tol in (("injected", replay_noise(c).to(gpu), TOL), ("philox", None, 1e-4)):
         x = b["x0"].clone()
-        rnd = b["loss"].compute_eubo(b["ts"], x, *b["args"], noise=noise)
+        extra = {k: v for k, v in b["kwargs"].items() if k == "initial_log_prob"}  # the DIS loss takes the prior log-density
+        rnd = b["loss"].compute_eubo(b["ts"], x, *b["args"], noise=noise, **extra)
         torch.cuda.synchronize()
         ex = gc.rel_err(x.cpu(), c["out_x"])  # compute_eubo noises x in place, like the reference
         ernd = float(((rnd.cpu().view(-1) - c["rnd"].view(-1)).abs() / tgt_scale).max())
