@@ -1,5 +1,6 @@
 // CMCD step loop (ControlledLangevinSDELoss.simulate, losses/oc.py:666-755) for a Bayesian logistic-regression
-// target (distr/logistic_regression.py) with a full-covariance or isotropic Gaussian prior, on gfx950.
+// target (distr/logistic_regression.py) or a diagonal Gaussian mixture target, with a full-covariance, diagonal or
+// isotropic Gaussian prior, on gfx950.
 //
 // The reference evaluates, per step, the drift net twice and the annealed score twice, each target score being
 // an autograd pass (4 per step with ScoreCtrl).  (t_k, y_k) of step k is (s_{k+1}, x_{k+1}) of step k+1 and the
@@ -43,51 +44,57 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   f16x8 xh[KB], xl[KB];
   split_tiles<NT>(x, xh, xl);
 
-  // ---- target score: prior part of the posterior + Xa^T r ----
-  f32x4 ts[NT], tm[NT];
+  f32x4 ts[NT];
+  if (s.target.kind != SDENG_DIST_LOGREG) {
+    // diagonal Gaussian / mixture target (distr/gauss.py:97-107, 124-126): tables prepared by k_dist_tables
+    gmm_score<NT>(x, s.target.tab, s.target.consts, 4, s.target.k, s.target.p0, g, ts);
+  } else {
+    // ---- logistic regression: prior part of the posterior + Xa^T r ----
+    f32x4 tm[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = feat(t, r, g);
-      const float xv = x[t][r];
-      float v = -xv * a.inv_w_scale2;                                   // logistic_regression.py:72
-      v = (f == s.d - 1) ? -(xv - a.c_mean) * a.inv_c_scale2 : v;       // :74
-      ts[t][r] = (f < s.d) ? v : 0.0f;
-    }
-    tm[t] = zero;
-  }
-  for (int pr = 0; pr < row_kb; ++pr) {  // 32 data rows per pass = one K-block of the Xa^T r product
-    asm volatile("" ::: "memory");
-    f32x4 lg[2], lm[2];
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      lg[o] = zero;
-      lm[o] = zero;
-      const int tile = 2 * pr + o;
-      if (tile < row_tiles) {  // wave-uniform
-        f32x4 acc[1] = {zero}, mx[1] = {zero};
-        dense_pre<KB, 1>(xh, xl, acc, mx, im_logit + static_cast<size_t>(tile) * KB * 2 * 64, lane);
-        lg[o] = acc[0];
-        lm[o] = mx[0];
+      for (int r = 0; r < 4; ++r) {
+        const int f = feat(t, r, g);
+        const float xv = x[t][r];
+        float v = -xv * a.inv_w_scale2;                                   // logistic_regression.py:72
+        v = (f == s.d - 1) ? -(xv - a.c_mean) * a.inv_c_scale2 : v;       // :74
+        ts[t][r] = (f < s.d) ? v : 0.0f;
       }
-      const f32x4 yv = load_tile4(a.y_pad, tile, g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        lg[o][r] = logreg_residual(__builtin_fmaf(lm[o][r], SD_LO_INV, lg[o][r]), yv[r], a.p_lo, a.p_hi);  // pad rows: Xa row = 0
+      tm[t] = zero;
     }
-    f16x8 rh, rl;
-    split8(lg[0], lg[1], rh, rl);
+    for (int pr = 0; pr < row_kb; ++pr) {  // 32 data rows per pass = one K-block of the Xa^T r product
+      asm volatile("" ::: "memory");
+      f32x4 lg[2], lm[2];
 #pragma unroll
-    for (int to = 0; to < NT; ++to) {
-      const f16x8 ah = im_grad[((to * row_kb + pr) * 2 + 0) * 64 + lane];
-      const f16x8 al = im_grad[((to * row_kb + pr) * 2 + 1) * 64 + lane];
-      ts[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rh, ts[to], 0, 0, 0);
-      tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rl, tm[to], 0, 0, 0);
-      tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, rh, tm[to], 0, 0, 0);
+      for (int o = 0; o < 2; ++o) {
+        lg[o] = zero;
+        lm[o] = zero;
+        const int tile = 2 * pr + o;
+        if (tile < row_tiles) {  // wave-uniform
+          f32x4 acc[1] = {zero}, mx[1] = {zero};
+          dense_pre<KB, 1>(xh, xl, acc, mx, im_logit + static_cast<size_t>(tile) * KB * 2 * 64, lane);
+          lg[o] = acc[0];
+          lm[o] = mx[0];
+        }
+        const f32x4 yv = load_tile4(a.y_pad, tile, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          lg[o][r] = logreg_residual(__builtin_fmaf(lm[o][r], SD_LO_INV, lg[o][r]), yv[r], a.p_lo, a.p_hi);  // pad rows: Xa row = 0
+      }
+      f16x8 rh, rl;
+      split8(lg[0], lg[1], rh, rl);
+#pragma unroll
+      for (int to = 0; to < NT; ++to) {
+        const f16x8 ah = im_grad[((to * row_kb + pr) * 2 + 0) * 64 + lane];
+        const f16x8 al = im_grad[((to * row_kb + pr) * 2 + 1) * 64 + lane];
+        ts[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rh, ts[to], 0, 0, 0);
+        tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rl, tm[to], 0, 0, 0);
+        tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, rh, tm[to], 0, 0, 0);
+      }
     }
+    fold_lo<NT>(ts, tm);
   }
-  fold_lo<NT>(ts, tm);
 
   // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
   const float hg2 = 0.5f * (s.cmcd_g * s.cmcd_g);
@@ -107,6 +114,13 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) b[t][r] = ts[t][r] * w_t + (-ps[t][r]) * w_1mt;
+  } else if (s.prior.kind == SDENG_DIST_GAUSS_DIAG) {  // Gauss.score (score_gauss, distr/gauss.py:124-126)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 pv = gauss_score_tile<NT>(x, s.prior.tab, g, t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[t][r] = ts[t][r] * w_t + pv[r] * w_1mt;
+    }
   } else {  // IsotropicGauss.score  distr/gauss.py:764-766
 #pragma unroll
     for (int t = 0; t < NT; ++t)

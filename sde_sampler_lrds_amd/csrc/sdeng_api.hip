@@ -107,7 +107,7 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.logz = o; o += align64(5 * SD_LOGZ_MAX_BLOCKS);
   L.cmcd = o;
   if (d->form == SDENG_FORM_CMCD) {
-    const int n = d->target.k > 0 ? d->target.k : 0;
+    const int n = (d->target.kind == SDENG_DIST_LOGREG && d->target.k > 0) ? d->target.k : 0;
     o += align64(sd_lr_logit_floats(DT, n) + sd_lr_grad_floats(DT, n)) + align64(32 * sd_lr_row_kb(n)) + align64(DT * sd_kb(DT) * 512) + align64(16 * DT);
   }
   L.total = o;
@@ -244,14 +244,16 @@ static int grid_for(int ntiles);
 static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s) {
   const int dpad = 16 * DT;
   if (DT > 4) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: d <= 64 (got %d)", d->d);
-  if (d->target.kind != SDENG_DIST_LOGREG) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: target must be LOGREG (kind %d)", d->target.kind);
-  const int n = d->target.k;
-  if (n < 1) return fail(SDENG_E_INVALID, "CMCD kernel: logistic regression without data rows");
+  const bool logreg = d->target.kind == SDENG_DIST_LOGREG;
+  if (!logreg && d->target.kind != SDENG_DIST_GMM_DIAG && d->target.kind != SDENG_DIST_GAUSS_DIAG)
+    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: target must be LOGREG, GMM_DIAG or GAUSS_DIAG (kind %d)", d->target.kind);
+  const int n = logreg ? d->target.k : 0;  // data rows held in LDS
+  if (logreg && n < 1) return fail(SDENG_E_INVALID, "CMCD kernel: logistic regression without data rows");
   if (static_cast<size_t>(cmcd_lds_floats(DT, n)) * sizeof(float) > 160 * 1024)
     return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: drift net + design matrix (%d rows x %d) need %zu bytes of LDS, 163840 available", n, d->d,
                 static_cast<size_t>(cmcd_lds_floats(DT, n)) * sizeof(float));
-  if (d->prior.kind != SDENG_DIST_GAUSS_FULL && d->prior.kind != SDENG_DIST_ISO_GAUSS)
-    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: prior must be GAUSS_FULL or ISO_GAUSS (kind %d)", d->prior.kind);
+  if (d->prior.kind != SDENG_DIST_GAUSS_FULL && d->prior.kind != SDENG_DIST_ISO_GAUSS && d->prior.kind != SDENG_DIST_GAUSS_DIAG)
+    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: prior must be GAUSS_FULL, GAUSS_DIAG or ISO_GAUSS (kind %d)", d->prior.kind);
   if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && d->net.ctrl_kind != SDENG_CTRL_SCORE)
     return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: ClippedCtrl or ScoreCtrl");
   if (!(d->flags & SDENG_FLAG_INIT_LOGP) || !(d->flags & SDENG_FLAG_TERM_TARGET))
@@ -269,10 +271,12 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   float* y_pad = image + align64(sd_lr_logit_floats(DT, n) + sd_lr_grad_floats(DT, n));
   float* prec = y_pad + align64(32 * sd_lr_row_kb(n));
   float* locp = prec + align64(DT * sd_kb(DT) * 512);
-  SD_HIP(sd_launch_logreg_images(d->target.loc, d->target.scale, n, d->d - 1, DT, image, y_pad, s));
   c.lr_image = image; c.y_pad = y_pad; c.n_rows = n;
-  c.inv_w_scale2 = 1.0f / (d->target.p0 * d->target.p0); c.c_mean = d->target.p1; c.inv_c_scale2 = 1.0f / (d->target.p2 * d->target.p2);
-  {  // sigmoid range with a gradient: inside clip(thr, 1 - thr) and inside the eps clamp of probs_to_logits
+  if (logreg) {
+    SD_HIP(sd_launch_logreg_images(d->target.loc, d->target.scale, n, d->d - 1, DT, image, y_pad, s));
+    c.inv_w_scale2 = 1.0f / (d->target.p0 * d->target.p0); c.c_mean = d->target.p1; c.inv_c_scale2 = 1.0f / (d->target.p2 * d->target.p2);
+  }
+  if (logreg) {  // sigmoid range with a gradient: inside clip(thr, 1 - thr) and inside the eps clamp of probs_to_logits
     const float thr = d->target.p3, eps = 1.1920928955078125e-07f;
     c.p_lo = thr > eps ? thr : eps;
     c.p_hi = (1.0f - thr) < (1.0f - eps) ? (1.0f - thr) : (1.0f - eps);
@@ -280,7 +284,7 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   if (d->prior.kind == SDENG_DIST_GAUSS_FULL) {
     SD_HIP(sd_launch_pack_square(d->prior.scale, d->prior.loc, d->d, DT, prec, locp, s));
     c.prec_pack = prec; c.prior_loc = locp;
-  } else {
+  } else if (d->prior.kind == SDENG_DIST_ISO_GAUSS) {
     c.iso_loc = d->prior.p0; c.inv_iso_var = 1.0f / d->prior.p3;
   }
   DistEvalArgs e;
@@ -288,6 +292,7 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   SD_HIP(sd_launch_dist_eval(e, s));
   a.rnd_init = ws + L.rnd_init;
   a.cmcd_g = d->cmcd_g; a.cmcd_clip = d->cmcd_clip;
+  a.target = target; a.prior = prior;
   c.s = a;
   if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
   SD_HIP((DT == 1 ? sd_launch_cmcd_1 : (DT == 2 ? sd_launch_cmcd_2 : sd_launch_cmcd_4))(c, grid_for(a.ntiles), s));

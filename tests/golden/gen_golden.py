@@ -401,6 +401,38 @@ def case_cmcd_logreg(name, B, N, seed, dt):
     finish(name, meta, arrays, res, draws)
 
 
+def case_cmcd_gmm(name, d, K, B, N, seed, prior_kind="iso"):
+    """CMCD on a Gaussian-mixture target (conf/solver/cmcd.yaml with conf/target/many_modes.yaml): IsotropicGauss(5) prior
+    (benchmark_utils.py cmcd defaults) or a diagonal Gauss prior (update_prior with a variance vector, solver/oc.py:291-303)."""
+    torch.manual_seed(seed)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
+    if prior_kind == "iso":
+        prior = r_gauss.IsotropicGauss(dim=d, scale=5.0)
+        x0 = 5.0 * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+        extra = dict(prior_scale=5.0)
+    else:
+        mean, var = 0.3 * torch.randn(d), 2.0 + torch.rand(d)
+        prior = r_gauss.Gauss(dim=d, loc=mean, scale=var.sqrt())
+        x0 = mean + var.sqrt() * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+        extra = {}
+    sde = r_sdes.ControlledLangevinSDE(target_score=target.score, prior_score=prior.score, diff_coeff=1.0, terminal_t=1.0, clip_score=1e5)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.01), target_score=target.score,
+                           detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
+    loss = r_oc.ControlledLangevinSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    ts = torch.linspace(0.0, 1.0, N + 1)
+    res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob,
+                                                         compute_weights=True, return_traj=True, use_ema=False))
+    (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob,
+                                                                   train=False))
+    meta = dict(kind="cmcd_gmm", d=d, K=K, B=B, N=N, seed=seed, diff_coeff=1.0, T=1.0, clip_langevin=1e5, clip_model=1e4, clip_score=1e4,
+                scale_score=1.0, prior_kind=prior_kind, **extra)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights,
+                  **pack_params("ctrl.", sd(ctrl)))
+    if prior_kind != "iso":
+        arrays.update(prior_loc=prior.loc.flatten(), prior_scale_vec=prior.scale.flatten())
+    finish(name, meta, arrays, res, draws)
+
+
 def case_dis(name, d, K, B, N, seed, kind):
     """DIS: kind='ei' -> DiscreteTimeReversalLossEI with ScoreCtrl; kind='orig' -> TimeReversalLoss with
     LerpCtrl (conf/solver/dis.yaml, conf/model/lerp.yaml, solver/oc.py:185-261)."""
@@ -530,6 +562,8 @@ CASES = {
     "dds_rings_d2": lambda n: case_dds(n, d=2, B=128, seed=32, rings=True),
     # config 4 (logreg d=61, CMCD), at the real step size 1/256
     "cmcd_logreg_d61": lambda n: case_cmcd_logreg(n, B=64, N=16, seed=41, dt=1.0 / 256),
+    "cmcd_gmm_iso_d16": lambda n: case_cmcd_gmm(n, d=16, K=4, B=64, N=32, seed=42, prior_kind="iso"),
+    "cmcd_gmm_diag_d40": lambda n: case_cmcd_gmm(n, d=40, K=4, B=64, N=32, seed=43, prior_kind="diag"),
     # DIS variants
     "dis_ei_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=51, kind="ei"),
     "dis_orig_lerp_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=64, seed=52, kind="orig"),
