@@ -1,14 +1,13 @@
 """Evaluation wrapper of the experiment notebooks (mirror of ``sde_sampler/additions/hacking.py:14-102``): the sampling
 metrics of ``Trainable.evaluate`` plus the EUBO-side metrics obtained from noising trajectories started at target
-samples (``loss.compute_eubo``).  Both passes are HIP launches; training (``run`` with steps left to do) is not on
-the HIP path and raises."""
+samples (``loss.compute_eubo``).  Both passes are HIP launches; ``run`` trains first (log-variance losses: HIP step loop
++ one batched autograd pass of the control per step)."""
 from __future__ import annotations
 
 import math
 
 import torch
 
-from .. import engine as E
 
 
 def evaluate_eubo(trainable, results, compute_eubo_last_arg, use_ema):
@@ -34,13 +33,24 @@ class TrainableWrapper:
         self.verbose = verbose
 
     def run(self, keep_training_metrics=False):
+        """additions/hacking.py:43-66: train for the remaining steps (log-variance training runs on the HIP step loop; KL
+        training raises), then evaluate with the EUBO-side metrics."""
+        import time
         t = self.trainable
-        if getattr(t, "train_steps", 0) > getattr(t, "n_steps", 0):
-            raise E.UnsupportedByEngine("TrainableWrapper.run trains the drift net (autograd through the step loop): not on the "
-                                        "HIP path yet (SURVEY.md 8f-1); evaluate() is")
+        if getattr(t, "optim", None) is None:
+            t.setup_optim()
+        training_metrics, training_time = [], 0.0
+        for i in range(t.n_steps, t.train_steps):
+            t0 = time.time()
+            metrics = t.step(i)
+            training_time += time.time() - t0
+            if keep_training_metrics:
+                training_metrics.append(metrics)
         results = self.evaluate(use_ema=getattr(t, "use_ema", False))
-        results.metrics["eval/training_time"] = 0.0
-        return (results, {}) if keep_training_metrics else results
+        results.metrics["eval/training_time"] = training_time
+        if keep_training_metrics:
+            return results, ({k: [m[k] for m in training_metrics if k in m] for k in training_metrics[0]} if training_metrics else {})
+        return results
 
     def compute_results_eubo(self, results, use_ema=True):
         t = self.trainable

@@ -414,6 +414,15 @@ def run(desc: L.Desc, x: torch.Tensor, keep: list, return_traj=False, noise=None
     return x_out, rnd, xs
 
 
+def philox_noise(seed: int, N: int, B: int, d: int, particle0: int, device) -> torch.Tensor:
+    """[N,B,d] normals of the step loop's counter-based stream (the kernel draws exactly these when no noise is injected)."""
+    lib = L.lib()
+    out = torch.empty(N, B, d, dtype=torch.float32, device=device)
+    for k in range(N):
+        L.check(lib.sdeng_philox_normal(int(seed), k, int(particle0), B, d, 0, out[k].data_ptr(), _stream_ptr(device)))
+    return out
+
+
 def logz_stats(rnd: torch.Tensor, want_weights=True):
     """sdeng_logz -> (stats[8] device tensor, weights [B,1] or None)."""
     require_gpu(rnd)

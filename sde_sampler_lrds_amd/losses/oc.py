@@ -57,6 +57,7 @@ class BaseOCLoss:
         # engine state
         self.seed = 1
         self.particle0 = 0
+        self.train_calls = 0
         self._coef_cache = {}
         self._cpu_sde = None
         self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
@@ -232,6 +233,42 @@ class EMReferenceSDELoss(BaseOCLoss):
         return self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
                               form=L.FORM_EM if self.kind == "em" else L.FORM_LIN, flags=L.FLAG_ITO, use_ema=use_ema,
                               return_traj=return_traj, noise=noise, ref=ref, coef_kw=dict(with_ref=ref[0] != "none"))
+
+    def __call__(self, ts, x, terminal_unnorm_log_prob, reference_log_prob):
+        """[TRAINING] losses/oc.py:364-394 for the log-variance methods.  With ``method in ('lv', 'lv_traj')`` the
+        trajectories are driven by the DETACHED control (:236-237, :474-475), so the states carry no graph and the step
+        loop is exactly the eval path: it runs as one HIP launch (trajectory and noise kept), and the log-weights are
+        then rebuilt with autograd by ONE batched pass of the control over all N*B (time, state) pairs:
+            rnd = sum_k c_k <u_k, u_k.detach() - u_k/2> + c'_k <u_k, z_k>  + [log p_ref - log pi~](x_N)
+        (:269-271/:284 for EM, :490-491/:499 for EI/DDPM-like).  KL training differentiates through the trajectory and
+        is not on this path."""
+        if self.method not in ("lv", "lv_traj"):
+            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path "
+                                        "(log-variance training is: method='lv')")
+        if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
+            raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built")
+        if self.traj_per_sample != 1:
+            x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
+        N, (B, d) = ts.numel() - 1, x.shape
+        # a fresh noise stream per training call (the reference consumes torch's global generator): call c uses the
+        # engine's Philox stream keyed by seed + c * golden-ratio increment; call 0 is the eval stream of ``seed``
+        seed_c = (int(self.seed) + 0x9E3779B97F4A7C15 * self.train_calls) & 0xFFFFFFFFFFFFFFFF
+        self.train_calls += 1
+        z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)
+        with torch.no_grad():
+            x_n, _, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
+                                       change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+            terminal = reference_log_prob(x_n).view((-1, 1)) - terminal_unnorm_log_prob(x_n)
+        coef = self._coef(ts, x.device, with_ref=E.resolve_reference(self.reference_ctrl)[0] != "none")
+        lin = self.kind != "em"
+        c_run = (2.0 * coef[:, 4]) if lin else coef[:, 4]  # omega (EI / DDPM-like)  or dt (EM)
+        c_ito = coef[:, 5]                                  # sqrt(omega)            or sqrt(dt)
+        t_rows = coef[:, 0].repeat_interleave(B).view(-1, 1)  # T - s_k for every row of step k
+        u = self.generative_ctrl(t_rows, xs[:-1].reshape(N * B, d))
+        run = (u * (u.detach() - 0.5 * u)).sum(dim=-1).view(N, B)
+        ito = (u * z.view(N * B, d)).sum(dim=-1).view(N, B)
+        rnd = (run * c_run.view(N, 1) + ito * c_ito.view(N, 1)).sum(dim=0).view(B, 1) + terminal
+        return self.compute_loss(rnd, samples=x_n)
 
     def compute_eubo(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, use_ema=False, *, noise=None):
         """losses/oc.py:298-362 (EM; inherited by the DDPM-like loss) and :512-568 (EI): noising trajectories started at

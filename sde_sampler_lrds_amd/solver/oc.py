@@ -148,13 +148,70 @@ class TrainableDiff:
         if "loss" in sd:
             self.loss.load_state_dict(sd["loss"])
 
-    def step(self, *a, **k):
-        raise NotImplementedError("training loop (solver/base.py:401-457) is not part of this engine (SURVEY.md 8f-1)")
+    # -- training (solver/base.py:265-310 optimiser set-up, :401-457 step; solver/oc.py:119-127 compute_loss) ----------------
+    def trainable_parameters(self):
+        return [p for p in self.generative_ctrl.parameters() if p.requires_grad]
 
-    run = step
+    def setup_optim(self):
+        o = dict(self.cfg.get("optim") or {})
+        self.optim = torch.optim.Adam(self.trainable_parameters(), **{"lr": 3e-4, **o})  # conf/solver/basic_oc_base.yaml:19-21
+        self.train_steps = self.cfg.get("train_steps", 0)
+        self.max_loss, self.max_grad, self.scale_loss = self.cfg.get("max_loss"), self.cfg.get("max_grad"), self.cfg.get("scale_loss")
+        self.grad_clip_norm = self.cfg.get("grad_clip_norm")
+        self.n_steps, self.n_steps_skip, self.train_ts = 0, 0, None
+
+    def compute_loss(self):
+        x = self.prior.sample((self.train_batch_size,)).to(self.device)
+        if self.train_ts is None:
+            self.train_ts = self.train_timesteps(device=self.device) if self._plain_grid() else self.train_timesteps().to(self.device)
+        return self._compute_loss(self.train_ts, x)
+
+    def _compute_loss(self, ts, x):
+        raise NotImplementedError
+
+    def step(self, step_id):
+        """One stochastic gradient step (solver/base.py:401-457): the loss's forward simulation is a HIP launch, its gradient
+        one batched autograd pass of the control (losses/oc.py ``__call__``)."""
+        import time as _time
+        if getattr(self, "optim", None) is None:
+            self.setup_optim()
+        t0 = _time.time()
+        self.optim.zero_grad()
+        loss, metrics = self.compute_loss()
+        if self.scale_loss is not None:
+            loss = self.scale_loss * loss
+        loss.backward()
+        params = self.trainable_parameters()
+        loss_ok = bool(loss.isfinite()) if self.max_loss is None else bool(loss.abs() <= self.max_loss)
+        if self.max_grad is None:
+            grad_ok = all(bool(p.grad.isfinite().all()) for p in params if p.grad is not None)
+        else:
+            mg = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
+            grad_ok = mg <= self.max_grad
+            metrics["train/max_grad"] = mg
+        if loss_ok and grad_ok:
+            if self.grad_clip_norm is not None:
+                metrics["train/grad_clip_norm"] = float(torch.nn.utils.clip_grad_norm_(params, self.grad_clip_norm))
+            self.optim.step()
+        else:
+            self.n_steps_skip += 1
+        metrics.update({"train/time_per_step": _time.time() - t0, "train/loss": loss.item(), "train/skipped_steps": self.n_steps_skip,
+                        "train/no_grad": sum(p.grad is None for p in params)})
+        self.n_steps += 1
+        return metrics
+
+    def run(self):
+        if getattr(self, "optim", None) is None:
+            self.setup_optim()
+        for step_id in range(self.n_steps, self.train_steps):
+            self.step(step_id)
+        return self.evaluate(use_ema=self.use_ema)
 
 
 class _InitialLogProbSolver(TrainableDiff):
+    def _compute_loss(self, ts, x):  # solver/oc.py:220-234
+        return self.loss(ts, x, self.clipped_target_unnorm_log_prob, initial_log_prob=self.prior.log_prob)
+
     def _compute_results(self, ts, x, use_ema=True, compute_weights=True, return_traj=True):
         return self.loss.eval(ts, x, self.clipped_target_unnorm_log_prob, use_ema=use_ema,
                               initial_log_prob=self.prior.log_prob, compute_weights=compute_weights, return_traj=return_traj)
@@ -188,6 +245,9 @@ class CMCD(_InitialLogProbSolver):
 
 
 class _ReferenceLogProbSolver(TrainableDiff):
+    def _compute_loss(self, ts, x):  # solver/oc.py:380-396, 453-465, 593-605
+        return self.loss(ts, x, self.clipped_target_unnorm_log_prob, self.reference_distr.log_prob)
+
     def _compute_results(self, ts, x, use_ema=True, compute_weights=True, return_traj=True):
         return self.loss.eval(ts, x, self.clipped_target_unnorm_log_prob, self.reference_distr.log_prob, use_ema=use_ema,
                               compute_weights=compute_weights, return_traj=return_traj)

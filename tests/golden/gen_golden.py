@@ -227,6 +227,40 @@ def case_eubo_dis(name, d, K, B, N, seed):
     save(name, meta, arrays)
 
 
+def case_train_lv(name, d, K, B, N, seed, integrator):
+    """One log-variance training evaluation of the RDS losses (losses/oc.py:364-394 with method='lv'): loss value and
+    the gradient w.r.t. every drift-net parameter under the replayed noise."""
+    torch.manual_seed(seed)
+    sde = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
+    ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
+    means = target.loc.clone() + 0.1 * torch.randn(K, d)
+    variances, weights = 0.5 * torch.ones(K, d), torch.ones(K)
+
+    def reference_ctrl(t, x):
+        return sde.marginal_gmm_score(t, x, means, variances, weights)
+
+    ref_distr = sde.marginal_gmm_distr(torch.tensor(0.0), means, variances, weights)
+    cls = {"ei": r_oc.EIReferenceSDELoss, "em": r_oc.EMReferenceSDELoss, "ddpm_like": r_oc.DDPMLikeReferenceSDELoss}[integrator]
+    loss = cls(ctrl, ctrl, sde=sde, method="lv", reference_ctrl=reference_ctrl)
+    ts = r_get_timesteps(0.0, 1.0, steps=N)
+    x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    orig = torch.randn_like
+    rep = Replay(seed)
+    torch.randn_like = rep
+    try:
+        value, _ = loss(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob)
+    finally:
+        torch.randn_like = orig
+    value.backward()
+    grads = {f"grad.{k}": p.grad.detach().clone() for k, p in ctrl.named_parameters()}
+    meta = dict(kind="train_lv", d=d, K=K, B=B, N=N, seed=seed, integrator=integrator, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0,
+                clip_model=1e4, loss=float(value), draws=rep.k)
+    arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights, ref_means=means,
+                  ref_vars=variances, ref_w=weights, **pack_params("ctrl.", sd(ctrl)), **grads)
+    save(name, meta, arrays)
+
+
 def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em"):
     """RDS with the default Gaussian reference (solver/oc.py:535-551): VP + IsotropicGauss prior, or
     PinnedBM + Delta prior (conf/solver/vp_rds.yaml, pbm_rds.yaml)."""
@@ -555,6 +589,9 @@ CASES = {
     "eubo_ei_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=62, integrator="ei"),
     "eubo_em_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=63, integrator="em"),
     "eubo_dis_ei_d8": lambda n: case_eubo_dis(n, d=8, K=4, B=64, N=32, seed=64),
+    # log-variance training evaluation (loss + gradients) of the RDS losses
+    "train_lv_ei_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=71, integrator="ei"),
+    "train_lv_em_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=72, integrator="em"),
     # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
     "pis_em_phi4_d100": lambda n: case_pis_phi4(n, d=100, B=64, N=32, seed=21, dt=5.0 / 512),
     # config 1 (TwoModes d=2, DDS) and the Rings target on the same solver

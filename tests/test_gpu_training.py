@@ -1,0 +1,59 @@
+"""Log-variance training direction: the HIP step loop + one batched autograd pass of the control must
+reproduce the reference's loss value and its gradient w.r.t. every drift-net parameter (fixtures generated from the real
+reference by tests/golden/gen_golden.py, same counter-based noise)."""
+import pytest
+import torch
+
+from sde_sampler_lrds_amd import engine as E
+from tests import build_cases as bc
+from tests import golden_cases as gc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["train_lv_ei_gmm_d16", "train_lv_em_gmm_d16"])
+def test_lv_training_loss_and_gradients_match_reference(gpu, name):
+    c = gc.load(name)
+    c.meta["kind"] = "rds_gmm"  # same objects as the simulate cases
+    b = bc.build(c, gpu)
+    loss = b["loss"]
+    loss.method = "lv"
+    ctrl = loss.generative_ctrl
+    for p in ctrl.parameters():
+        p.grad = None
+    value, metrics = loss(b["ts"], b["x0"], *b["args"])
+    value.backward()
+    assert abs(float(value) - c.meta["loss"]) < 2e-4 * max(1.0, abs(c.meta["loss"])), (float(value), c.meta["loss"])
+    worst = 0.0
+    for k, p in ctrl.named_parameters():
+        ref = c["grad." + k]
+        err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
+        worst = max(worst, err)
+        assert err < 2e-3, (k, err)
+    print(f"{name}: loss {float(value):.6f} vs {c.meta['loss']:.6f}; worst relative gradient error {worst:.2e}")
+    assert "train/n_filtered_cumulative" in metrics
+
+
+@pytest.mark.gpu
+def test_kl_training_is_refused(gpu):
+    c = gc.load("train_lv_ei_gmm_d16")
+    c.meta["kind"] = "rds_gmm"
+    b = bc.build(c, gpu)
+    b["loss"].method = "kl"
+    with pytest.raises(E.UnsupportedByEngine):
+        b["loss"](b["ts"], b["x0"], *b["args"])
+
+
+@pytest.mark.gpu
+def test_training_steps_reduce_the_loss(gpu):
+    """make_model -> TrainableWrapper.run(): a few hundred Adam steps of log-variance training on a small mixture."""
+    from sde_sampler_lrds_amd.additions.hacking import TrainableWrapper
+    from sde_sampler_lrds_amd.experiments.benchmark_utils import make_model, make_target_details
+    tgt = make_target_details("many_modes", dim=8, n_modes=4)
+    K, d = 4, 8
+    model = make_model("vp-ref", "default", "lv", "ei", "base_zero_init", "uniform", dict(sigma=2.0), tgt,
+                       dict(train_steps=150, train_batch_size=512, eval_batch_size=2048), optim_details=dict(lr=3e-3), n_steps=32)
+    before = model.evaluate().metrics["eval/lv_loss"]
+    res, train = TrainableWrapper(model, verbose=False).run(keep_training_metrics=True)
+    after = res.metrics["eval/lv_loss"]
+    print(f"eval/lv_loss {before:.3f} -> {after:.3f} after {len(train['train/loss'])} steps; eubo {res.metrics.get('eval/eubo')}")
+    assert len(train["train/loss"]) == 150 and after < 0.7 * before
