@@ -7,9 +7,10 @@ update and log-RND accumulation run inside a single persistent gfx950 kernel.
 
 What is on the HIP path: the eval / sampling direction (``change_sde_ctrl=False``), i.e. what
 ``Trainable.evaluate`` times as ``eval/sample_time`` (solver/oc.py:148-158).  ``compute_eubo`` (the noising loops of
-SURVEY.md 8f-2) is a HIP launch too for the RDS losses and DiscreteTimeReversalLossEI.  The training direction
-(``__call__``: autograd through the net, 8f-1) and the CMCD ``compute_eubo`` are not built yet: they raise instead of
-silently running a PyTorch loop.
+SURVEY.md 8f-2) is a HIP launch too for the RDS losses and DiscreteTimeReversalLossEI.  The training direction (``__call__``,
+8f-1) is built for the log-variance methods (``_lv_loss``: HIP step loop + one batched autograd pass of the control); KL
+training, the CMCD / TimeReversal losses' training and the CMCD ``compute_eubo`` raise instead of silently running a PyTorch
+loop.
 
 Extra, engine-only knobs (keyword-only, default to the reference behaviour):
   * ``noise=[N,B,d]`` injects the normals (replays the reference's ``randn_like`` stream, parity mode);
@@ -107,6 +108,42 @@ class BaseOCLoss:
 
     def state_dict(self) -> dict:
         return {"n_filtered": self.n_filtered}
+
+    def _lv_loss(self, ts, x, simulate, terminal, *, lin, coef_kw=None, rnd0=None, ito=True):
+        """Log-variance training value (losses/oc.py ``__call__`` of every loss, method in ('lv', 'lv_traj')).  The
+        trajectories are driven by the DETACHED control (generative_and_sde_ctrl, :83-103), so the states carry no graph
+        and the step loop is exactly the eval path: it runs as one HIP launch (``simulate(x, z)`` with the trajectory and
+        the noise kept), and the log-weights are then rebuilt with autograd by ONE batched pass of the control over all
+        N*B (time, state) pairs:
+            rnd = rnd0 + sum_k c_k <u_k, u_k.detach() - u_k/2> + c'_k <u_k, z_k> + terminal(x_N)
+        (:269-271, :284 EM; :490-491, :499 EI / DDPM-like; :957-958, :965 DIS; :1361-1383 DDS).  KL training differentiates
+        through the trajectory and is not on this path."""
+        if self.method not in ("lv", "lv_traj"):
+            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path "
+                                        "(log-variance training is: method='lv')")
+        if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
+            raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built")
+        if self.traj_per_sample != 1:
+            x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
+        N, (B, d) = ts.numel() - 1, x.shape
+        # a fresh noise stream per training call (the reference consumes torch's global generator): call c uses the
+        # engine's Philox stream keyed by seed + c * golden-ratio increment; call 0 is the eval stream of ``seed``
+        seed_c = (int(self.seed) + 0x9E3779B97F4A7C15 * self.train_calls) & 0xFFFFFFFFFFFFFFFF
+        self.train_calls += 1
+        z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)
+        with torch.no_grad():
+            x_n, _, xs = simulate(x, z)
+            const = terminal(x_n)
+            if rnd0 is not None:
+                const = const + rnd0(x).view((-1, 1))
+        coef = self._coef(ts, x.device, **(coef_kw or {}))
+        c_run = (2.0 * coef[:, 4]) if lin else coef[:, 4]  # omega | beta^2 sigma^2 (LIN forms)  or dt (EM)
+        t_rows = coef[:, 0].repeat_interleave(B).view(-1, 1)  # the net's time for every row of step k
+        u = self.generative_ctrl(t_rows, xs[:-1].reshape(N * B, d))
+        rnd = ((u * (u.detach() - 0.5 * u)).sum(dim=-1).view(N, B) * c_run.view(N, 1)).sum(dim=0)
+        if ito:
+            rnd = rnd + ((u * z.view(N * B, d)).sum(dim=-1).view(N, B) * coef[:, 5].view(N, 1)).sum(dim=0)
+        return self.compute_loss(rnd.view(B, 1) + const, samples=x_n)
 
     # ---- engine plumbing ---------------------------------------------------------------------
     def _ctrl(self, use_ema):
@@ -235,40 +272,12 @@ class EMReferenceSDELoss(BaseOCLoss):
                               return_traj=return_traj, noise=noise, ref=ref, coef_kw=dict(with_ref=ref[0] != "none"))
 
     def __call__(self, ts, x, terminal_unnorm_log_prob, reference_log_prob):
-        """[TRAINING] losses/oc.py:364-394 for the log-variance methods.  With ``method in ('lv', 'lv_traj')`` the
-        trajectories are driven by the DETACHED control (:236-237, :474-475), so the states carry no graph and the step
-        loop is exactly the eval path: it runs as one HIP launch (trajectory and noise kept), and the log-weights are
-        then rebuilt with autograd by ONE batched pass of the control over all N*B (time, state) pairs:
-            rnd = sum_k c_k <u_k, u_k.detach() - u_k/2> + c'_k <u_k, z_k>  + [log p_ref - log pi~](x_N)
-        (:269-271/:284 for EM, :490-491/:499 for EI/DDPM-like).  KL training differentiates through the trajectory and
-        is not on this path."""
-        if self.method not in ("lv", "lv_traj"):
-            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path "
-                                        "(log-variance training is: method='lv')")
-        if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
-            raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built")
-        if self.traj_per_sample != 1:
-            x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
-        N, (B, d) = ts.numel() - 1, x.shape
-        # a fresh noise stream per training call (the reference consumes torch's global generator): call c uses the
-        # engine's Philox stream keyed by seed + c * golden-ratio increment; call 0 is the eval stream of ``seed``
-        seed_c = (int(self.seed) + 0x9E3779B97F4A7C15 * self.train_calls) & 0xFFFFFFFFFFFFFFFF
-        self.train_calls += 1
-        z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)
-        with torch.no_grad():
-            x_n, _, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
-                                       change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
-            terminal = reference_log_prob(x_n).view((-1, 1)) - terminal_unnorm_log_prob(x_n)
-        coef = self._coef(ts, x.device, with_ref=E.resolve_reference(self.reference_ctrl)[0] != "none")
-        lin = self.kind != "em"
-        c_run = (2.0 * coef[:, 4]) if lin else coef[:, 4]  # omega (EI / DDPM-like)  or dt (EM)
-        c_ito = coef[:, 5]                                  # sqrt(omega)            or sqrt(dt)
-        t_rows = coef[:, 0].repeat_interleave(B).view(-1, 1)  # T - s_k for every row of step k
-        u = self.generative_ctrl(t_rows, xs[:-1].reshape(N * B, d))
-        run = (u * (u.detach() - 0.5 * u)).sum(dim=-1).view(N, B)
-        ito = (u * z.view(N * B, d)).sum(dim=-1).view(N, B)
-        rnd = (run * c_run.view(N, 1) + ito * c_ito.view(N, 1)).sum(dim=0).view(B, 1) + terminal
-        return self.compute_loss(rnd, samples=x_n)
+        """[TRAINING] losses/oc.py:364-394 (see BaseOCLoss._lv_loss)."""
+        def sim(xx, z):
+            return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
+                                 change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+        return self._lv_loss(ts, x, sim, lambda xn: reference_log_prob(xn).view((-1, 1)) - terminal_unnorm_log_prob(xn),
+                             lin=self.kind != "em", coef_kw=dict(with_ref=E.resolve_reference(self.reference_ctrl)[0] != "none"))
 
     def compute_eubo(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, use_ema=False, *, noise=None):
         """losses/oc.py:298-362 (EM; inherited by the DDPM-like loss) and :512-568 (EI): noising trajectories started at
@@ -391,6 +400,15 @@ class DiscreteTimeReversalLossEI(_InitialLogProbLoss):
         return self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=init,
                               form=L.FORM_LIN, flags=L.FLAG_ITO, use_ema=use_ema, return_traj=return_traj, noise=noise)
 
+    def __call__(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None):
+        """[TRAINING] losses/oc.py:1038-1066, log-variance methods (rnd0 = log p_prior(x0), terminal -log pi~)."""
+        def sim(xx, z):
+            return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=None, train=True,
+                                 change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+        if self.method in ("kl", "kl_ito"):
+            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
+        return self._lv_loss(ts, x, sim, lambda xn: -terminal_unnorm_log_prob(xn), lin=True, rnd0=initial_log_prob)
+
     def compute_eubo(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, use_ema=False, *, noise=None):
         """losses/oc.py:980-1036: noising trajectories from target samples (no reference; cost 0.5|u|^2 omega, Ito term,
         + log p_prior of the noised samples), one HIP launch.  ``x`` is noised in place like upstream."""
@@ -443,6 +461,14 @@ class ExponentialIntegratorSDELoss(BaseOCLoss):
         return self._simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
                               form=L.FORM_LIN, flags=L.FLAG_ITO if compute_ito_int else 0, use_ema=use_ema,
                               return_traj=return_traj, noise=noise, coef_kw=dict(alpha=self.alpha, sigma=self.sigma))
+
+    def __call__(self, ts, x, terminal_unnorm_log_prob, reference_log_prob):
+        """[TRAINING] losses/oc.py:1399-1428, log-variance methods (compute_ito_int = True for them)."""
+        def sim(xx, z):
+            return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
+                                 compute_ito_int=True, change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+        return self._lv_loss(ts, x, sim, lambda xn: reference_log_prob(xn).view((-1, 1)) - terminal_unnorm_log_prob(xn), lin=True,
+                             coef_kw=dict(alpha=self.alpha, sigma=self.sigma))
 
     def eval(self, ts, x, terminal_unnorm_log_prob, reference_log_prob=None, compute_weights=True, return_traj=True,
              use_ema=True, *, noise=None) -> Results:

@@ -261,6 +261,72 @@ def case_train_lv(name, d, K, B, N, seed, integrator):
     save(name, meta, arrays)
 
 
+def _train_fixture(name, meta, arrays, ctrl, call):
+    """Run ``call()`` (a reference loss __call__) under the replayed noise, back-propagate, save loss + gradients."""
+    orig = torch.randn_like
+    rep = Replay(meta["seed"])
+    torch.randn_like = rep
+    try:
+        value, _ = call()
+    finally:
+        torch.randn_like = orig
+    value.backward()
+    grads = {f"grad.{k}": p.grad.detach().clone() for k, p in ctrl.named_parameters() if p.grad is not None}
+    save(name, dict(meta, loss=float(value), draws=rep.k), dict(arrays, **pack_params("ctrl.", sd(ctrl)), **grads))
+
+
+def case_train_lv_dis(name, d, K, B, N, seed):
+    """DiscreteTimeReversalLossEI.__call__ (losses/oc.py:1038-1066), method='lv', ScoreCtrl on a mixture target."""
+    torch.manual_seed(seed)
+    sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=1.0)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.2), target_score=target.score,
+                           detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
+    loss = r_oc.DiscreteTimeReversalLossEI(ctrl, ctrl, sde=sde, method="lv")
+    ts = r_get_timesteps(0.0, 1.0, steps=N)
+    x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    meta = dict(kind="train_lv_dis", d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0, clip_model=1e4,
+                clip_score=1e4, scale_score=1.0)
+    arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
+    _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
+
+
+def case_train_lv_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0):
+    """ExponentialIntegratorSDELoss.__call__ (losses/oc.py:1399-1428), method='lv', TwoModes target."""
+    torch.manual_seed(seed)
+    target = r_gauss.TwoModes(dim=d, a=1.0, ill_conditioned="not", n_reference_samples=10)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=sigma)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.01), target_score=target.score,
+                           detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
+    loss = r_oc.ExponentialIntegratorSDELoss(ctrl, ctrl, sde=None, method="lv", alpha=1.0, sigma=sigma)
+    ts = r_get_timesteps(0.0, end, dt=dt, rescale_t="cosine")
+    x0 = sigma * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    meta = dict(kind="train_lv_dds", d=d, B=B, N=len(ts) - 1, seed=seed, alpha=1.0, sigma=sigma, clip_model=1e4, clip_score=1e4,
+                scale_score=1.0, dt=dt, end=end)
+    arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
+    _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, prior.log_prob))
+
+
+def case_train_lv_pis(name, d, B, N, seed, dt):
+    """EMReferenceSDELoss.__call__ without a reference (PIS, losses/oc.py:364-394), method='lv', phi^4 target."""
+    torch.manual_seed(seed)
+    g, Tstar = math.sqrt(0.2), 5.0
+    sde = r_sdes.ScaledBM(diff_coeff=g, terminal_t=Tstar)
+    target = r_phi.PhiFour(a=0.1, b=0.0, dim=d, dim_phys=1, beta=20.0)
+    prior = r_delta.Delta(dim=d)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.02), target_score=target.score,
+                           detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
+    ref_distr = sde.marginal_distr(t=sde.terminal_t, x_init=prior.loc)
+    loss = r_oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    ts = torch.linspace(0.0, N * dt, N + 1)
+    x0 = prior.sample((B,))
+    meta = dict(kind="train_lv_pis", d=d, B=B, N=N, seed=seed, diff_coeff=g, T=Tstar, a=0.1, b=0.0, beta=20.0, clip_model=1e4,
+                clip_score=1e4, scale_score=1.0)
+    arrays = dict(ts=ts, x0=x0, ref_loc=ref_distr.loc, ref_scale=ref_distr.scale)
+    _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob))
+
+
 def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em"):
     """RDS with the default Gaussian reference (solver/oc.py:535-551): VP + IsotropicGauss prior, or
     PinnedBM + Delta prior (conf/solver/vp_rds.yaml, pbm_rds.yaml)."""
@@ -592,6 +658,9 @@ CASES = {
     # log-variance training evaluation (loss + gradients) of the RDS losses
     "train_lv_ei_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=71, integrator="ei"),
     "train_lv_em_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=72, integrator="em"),
+    "train_lv_dis_ei_d8": lambda n: case_train_lv_dis(n, d=8, K=4, B=64, N=32, seed=73),
+    "train_lv_dds_d2": lambda n: case_train_lv_dds(n, d=2, B=128, seed=74),
+    "train_lv_pis_phi4_d100": lambda n: case_train_lv_pis(n, d=100, B=32, N=16, seed=75, dt=5.0 / 512),
     # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
     "pis_em_phi4_d100": lambda n: case_pis_phi4(n, d=100, B=64, N=32, seed=21, dt=5.0 / 512),
     # config 1 (TwoModes d=2, DDS) and the Rings target on the same solver

@@ -9,22 +9,28 @@ from tests import build_cases as bc
 from tests import golden_cases as gc
 
 
+KINDS = {"train_lv": "rds_gmm", "train_lv_dis": "dis_ei", "train_lv_dds": "dds", "train_lv_pis": "pis_phi4"}  # objects as in the simulate cases
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["train_lv_ei_gmm_d16", "train_lv_em_gmm_d16"])
+@pytest.mark.parametrize("name", ["train_lv_ei_gmm_d16", "train_lv_em_gmm_d16", "train_lv_dis_ei_d8", "train_lv_dds_d2", "train_lv_pis_phi4_d100"])
 def test_lv_training_loss_and_gradients_match_reference(gpu, name):
     c = gc.load(name)
-    c.meta["kind"] = "rds_gmm"  # same objects as the simulate cases
+    c.meta["kind"] = KINDS[c.meta["kind"]]
     b = bc.build(c, gpu)
     loss = b["loss"]
     loss.method = "lv"
     ctrl = loss.generative_ctrl
     for p in ctrl.parameters():
         p.grad = None
-    value, metrics = loss(b["ts"], b["x0"], *b["args"])
+    kw = {k: v for k, v in b["kwargs"].items() if k == "initial_log_prob"}
+    value, metrics = loss(b["ts"], b["x0"], *b["args"], **kw)
     value.backward()
     assert abs(float(value) - c.meta["loss"]) < 2e-4 * max(1.0, abs(c.meta["loss"])), (float(value), c.meta["loss"])
     worst = 0.0
     for k, p in ctrl.named_parameters():
+        if "grad." + k not in c.a:
+            continue
         ref = c["grad." + k]
         err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
         worst = max(worst, err)
