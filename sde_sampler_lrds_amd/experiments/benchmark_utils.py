@@ -112,7 +112,7 @@ def make_model(solver_type, ref_type, loss_type, integrator_type, model_type, ti
         ts["start"] = 1e-3
     cfg = dict(prior=prior, sde=sde, model=model_types[model_type], loss=loss, timesteps=ts,
                eval_batch_size=training_details["eval_batch_size"], train_batch_size=training_details["train_batch_size"],
-               train_steps=training_details.get("train_steps", 0), optim=dict(optim_details or {}))  # benchmark_utils.py:181-183, 215-217
+               train_steps=training_details.get("train_steps", 0), optim=dict(optim_details or {}), use_ema=use_ema)  # benchmark_utils.py:181-183, 215-217
     model = cls(cfg, _make_target(target_details), device=device)
     if "ref" in solver_type:
         if ref_type == "gaussian":

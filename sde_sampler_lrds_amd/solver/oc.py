@@ -62,7 +62,8 @@ class TrainableDiff:
         self.train_timesteps = partial(get_timesteps, **ts_cfg)
         self.eval_timesteps = self.train_timesteps
         self.eval_ts = None
-        self.use_ema = False
+        self.use_ema = bool(cfg.get("use_ema", False))
+        self.ema_steps, self.ema_decay = cfg.get("ema_steps", 10), cfg.get("ema_decay", 0.995)  # conf/solver/basic_oc_base.yaml:23-26
         # solver/oc.py:37 sets True for every diffusion solver and :356/:436 switch it off for PIS/DDS; here it is on
         # only where compute_eubo is a HIP launch (the reference-SDE losses of RDS)
         self.eubo_available = False
@@ -92,7 +93,13 @@ class TrainableDiff:
         else:
             self.sde = self.make_sde()
         self.generative_ctrl = build_ctrl(self.cfg["model"], self.target.dim, self.sde, self.prior, self.target)
-        self.generative_ctrl_ema = self.generative_ctrl
+        if self.use_ema:  # solver/oc.py:69-78
+            total = self.cfg.get("train_steps", 1) / (self.train_batch_size * self.ema_steps)
+            alpha = min(1.0, (1.0 - self.ema_decay) / total)
+            self.generative_ctrl_ema = torch.optim.swa_utils.AveragedModel(
+                self.generative_ctrl, multi_avg_fn=torch.optim.swa_utils.get_ema_multi_avg_fn(1.0 - alpha))
+        else:
+            self.generative_ctrl_ema = self.generative_ctrl
 
     def make_loss(self, **extra):
         c = dict(self.cfg["loss"])
@@ -103,8 +110,8 @@ class TrainableDiff:
         return loss
 
     def modules(self):
-        return [m for m in (self.target, self.prior, self.sde, self.generative_ctrl, getattr(self, "_reference", None),
-                            getattr(self, "reference_distr", None)) if isinstance(m, torch.nn.Module)]
+        return [m for m in (self.target, self.prior, self.sde, self.generative_ctrl, getattr(self, "generative_ctrl_ema", None),
+                            getattr(self, "_reference", None), getattr(self, "reference_distr", None)) if isinstance(m, torch.nn.Module)]
 
     def to(self, device):
         self.device = torch.device(device)
@@ -193,6 +200,8 @@ class TrainableDiff:
             if self.grad_clip_norm is not None:
                 metrics["train/grad_clip_norm"] = float(torch.nn.utils.clip_grad_norm_(params, self.grad_clip_norm))
             self.optim.step()
+            if self.use_ema and step_id % self.ema_steps == 0:
+                self.generative_ctrl_ema.update_parameters(self.generative_ctrl)
         else:
             self.n_steps_skip += 1
         metrics.update({"train/time_per_step": _time.time() - t0, "train/loss": loss.item(), "train/skipped_steps": self.n_steps_skip,

@@ -26,7 +26,7 @@ def test_lv_training_loss_and_gradients_match_reference(gpu, name):
     kw = {k: v for k, v in b["kwargs"].items() if k == "initial_log_prob"}
     value, metrics = loss(b["ts"], b["x0"], *b["args"], **kw)
     value.backward()
-    assert abs(float(value) - c.meta["loss"]) < 2e-4 * max(1.0, abs(c.meta["loss"])), (float(value), c.meta["loss"])
+    assert abs(float(value.detach()) - c.meta["loss"]) < 2e-4 * max(1.0, abs(c.meta["loss"])), (float(value.detach()), c.meta["loss"])
     worst = 0.0
     for k, p in ctrl.named_parameters():
         if "grad." + k not in c.a:
@@ -35,7 +35,7 @@ def test_lv_training_loss_and_gradients_match_reference(gpu, name):
         err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
         worst = max(worst, err)
         assert err < 2e-3, (k, err)
-    print(f"{name}: loss {float(value):.6f} vs {c.meta['loss']:.6f}; worst relative gradient error {worst:.2e}")
+    print(f"{name}: loss {float(value.detach()):.6f} vs {c.meta['loss']:.6f}; worst relative gradient error {worst:.2e}")
     assert "train/n_filtered_cumulative" in metrics
 
 
@@ -63,3 +63,18 @@ def test_training_steps_reduce_the_loss(gpu):
     after = res.metrics["eval/lv_loss"]
     print(f"eval/lv_loss {before:.3f} -> {after:.3f} after {len(train['train/loss'])} steps; eubo {res.metrics.get('eval/eubo')}")
     assert len(train["train/loss"]) == 150 and after < 0.7 * before
+
+
+@pytest.mark.gpu
+def test_ema_weights_are_used_for_evaluation(gpu):
+    from sde_sampler_lrds_amd.experiments.benchmark_utils import make_model, make_target_details
+    tgt = make_target_details("many_modes", dim=8, n_modes=4)
+    model = make_model("vp-ref", "default", "lv", "ei", "base_zero_init", "uniform", dict(sigma=2.0), tgt,
+                       dict(train_steps=20, train_batch_size=256, eval_batch_size=512), optim_details=dict(lr=3e-3), n_steps=16, use_ema=True)
+    assert type(model.generative_ctrl_ema).__name__ == "AveragedModel"
+    model.run()
+    w, w_ema = model.generative_ctrl.base_model.out_layer.weight, model.generative_ctrl_ema.module.base_model.out_layer.weight
+    assert not torch.equal(w, w_ema) and int(model.generative_ctrl_ema.n_averaged) >= 2
+    a = model.evaluate(use_ema=True).metrics["eval/elbo"]
+    b = model.evaluate(use_ema=False).metrics["eval/elbo"]
+    assert a != b  # the EMA copy and the live net drive different samplers
