@@ -130,9 +130,11 @@ def main():
 
     # bring the GPU to its sustained clocks first: the same pass, untimed (the first ~40 ms after idle run ~15 %
     # slower than steady state: tools/probe_scaling.py)
+    # (rank-local passes WITHOUT the all-gather: the number of spin-up passes is time-based and may differ between ranks)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < a.spinup:
-        one_pass().result()
+        _, rnd_spin, _ = loss.simulate(ts, x0, *args)
+        parallel.global_results_async(rnd_spin, None).result()
     for _ in range(a.warmup):
         one_pass().result()
     torch.cuda.synchronize()
