@@ -128,6 +128,10 @@ def main():
         x, rnd, _ = loss.simulate(ts, x0, *args)
         return parallel.global_results_async(rnd, dist)
 
+    if dist is not None:  # create the RCCL communicator now (~20 ms the first time): an idle gap right before the timed
+        dist.barrier()    # region would let the clocks drop again
+        one_pass().result()
+        dist.barrier()
     # bring the GPU to its sustained clocks first: the same pass, untimed (the first ~40 ms after idle run ~15 %
     # slower than steady state: tools/probe_scaling.py)
     # (rank-local passes WITHOUT the all-gather: the number of spin-up passes is time-based and may differ between ranks)
