@@ -99,21 +99,19 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
   const float hg2 = 0.5f * (s.cmcd_g * s.cmcd_g);
   if (a.prec_pack) {  // GaussFull: -P (w - mu)   distr/gauss.py:129-135
-    f32x4 df[NT], ps[NT], pm[NT];
+    f32x4 df[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      df[t] = x[t] - load_tile4(a.prior_loc, t, g);
-      ps[t] = zero;
-      pm[t] = zero;
-    }
+    for (int t = 0; t < NT; ++t) df[t] = x[t] - load_tile4(a.prior_loc, t, g);
     f16x8 dh[KB], dl[KB];
     split_tiles<NT>(df, dh, dl);
-    dense_pre<KB, NT>(dh, dl, ps, pm, reinterpret_cast<const f16x8*>(a.prec_pack), lane);
-    fold_lo<NT>(ps, pm);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {  // one output tile at a time: 2*KB A-operand vectors live instead of 2*KB*NT
+      f32x4 ps[1] = {zero}, pm[1] = {zero};
+      dense_pre<KB, 1>(dh, dl, ps, pm, reinterpret_cast<const f16x8*>(a.prec_pack) + static_cast<size_t>(t) * KB * 2 * 64, lane);
+      fold_lo<1>(ps, pm);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) b[t][r] = ts[t][r] * w_t + (-ps[t][r]) * w_1mt;
+      for (int r = 0; r < 4; ++r) b[t][r] = ts[t][r] * w_t + (-ps[0][r]) * w_1mt;
+    }
   } else if (s.prior.kind == SDENG_DIST_GAUSS_DIAG) {  // Gauss.score (score_gauss, distr/gauss.py:124-126)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -192,8 +190,18 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     float rnd = 0.0f;
     if (s.rnd_init) rnd = (live ? s.rnd_init[row] : 0.0f);  // rnd0 = log p_prior(x0)  (losses/oc.py:695-699)
     if (s.xs_out) store_rows<NT>(s.xs_out, trash, row, s.d, live, g, x);
-    f32x4 u_s[NT], b_s[NT];
-    if (s.N > 0) cmcd_eval<NT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, lane, u_s, b_s);
+    // carried between steps: w_s = b_s/g + u_s, the only combination of (u_s, b_s) the step needs:
+    //   y = x + (b_s + u_s g) dt + g db = x + g w_s dt + g db ;   cost = (b_s + b_t)/g + u_s - u_t = w_s + (b_t/g - u_t)
+    // (16 registers per 64 features less than carrying u_s and b_s; identical arithmetic for g = 1, the conf default)
+    f32x4 w_s[NT];
+    if (s.N > 0) {
+      f32x4 u0[NT], b0[NT];
+      cmcd_eval<NT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, lane, u0, b0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w_s[t][r] = b0[t][r] * inv_g + u0[t][r];
+    }
 
     for (int k = 0; k < s.N; ++k) {
       const float* cf = s.coef + static_cast<size_t>(k) * SDENG_NCOEF;
@@ -214,30 +222,29 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
         for (int r = 0; r < 4; ++r) {
           const float dbv = sqdt * z[r];
           db[t][r] = dbv;
-          x[t][r] = x[t][r] + (b_s[t][r] + u_s[t][r] * gg) * dt + gg * dbv;
+          x[t][r] = x[t][r] + (w_s[t][r] * gg) * dt + gg * dbv;
         }
       }
-      f32x4 u_t[NT], b_t[NT];
-      cmcd_eval<NT>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t);
       // cost = (b_s + b_t)/g + u_s - u_t ;  rnd += 0.5 |cost|^2 dt + <cost, db>   (losses/oc.py:737-742)
       float c2 = 0.0f, cdb = 0.0f;
+      {
+        f32x4 u_t[NT], b_t[NT];
+        cmcd_eval<NT>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float c = ((b_s[t][r] + b_t[t][r]) * inv_g + u_s[t][r]) - u_t[t][r];
-          c2 = __builtin_fmaf(c, c, c2);
-          cdb = __builtin_fmaf(c, db[t][r], cdb);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float bg = b_t[t][r] * inv_g;
+            const float c = w_s[t][r] + (bg - u_t[t][r]);
+            c2 = __builtin_fmaf(c, c, c2);
+            cdb = __builtin_fmaf(c, db[t][r], cdb);
+            w_s[t][r] = bg + u_t[t][r];
+          }
+      }
       c2 = group_sum(c2);
       cdb = group_sum(cdb);
       rnd += (0.5f * c2) * dt;
       rnd += cdb;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        u_s[t] = u_t[t];
-        b_s[t] = b_t[t];
-      }
       if (s.xs_out) store_rows<NT>(s.xs_out + static_cast<size_t>(k + 1) * s.B * s.d, trash, row, s.d, live, g, x);
     }
     store_rows<NT>(s.x_out, trash, row, s.d, live, g, x);
