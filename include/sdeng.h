@@ -73,6 +73,9 @@ extern "C" {
  *   [8]  lerp weight t/T  lerp weight        (unused)     LerpCtrl only
  *   [9]  s(tau)   [10] s(tau)^2*sigma_sq(tau)   [11] s(tau)^2   reference marginal (eq/sdes.py:228-229,247)
  *   [12..15] reserved
+ * SDENG_FORM_EUBO (rows in iteration order): [0] t_net = T - s, [1] mean factor, [2] control gain (1, or 1/g with
+ *   use_rescaling), [3] std factor, [4] running-cost weight (omega | dt g^2), [5] Ito weight (sqrt omega | std/mean),
+ *   [6] <u,x> weight (0 | 1/mean - 1 + drift_coeff dt), [9..11] reference marginal at t_net.
  */
 #define SDENG_NCOEF 16
 
