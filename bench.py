@@ -29,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 (dense, = vector fp32 peak)
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 MFMA = packed-fp32 vector peak (256 FLOP/clk/CU)
 
 
 def host_cores() -> int:

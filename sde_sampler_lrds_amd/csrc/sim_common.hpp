@@ -8,7 +8,7 @@
 //
 //        feat(t, r, g) = 16 t + 4 g + r                 t = feature tile, r = 0..3
 //
-// which is exactly the C/D layout of v_mfma_f32_16x16x4_f32 when the product is computed as Y^T = W * X^T
+// which is exactly the C/D layout of the 16x16 MFMAs (v_mfma_f32_16x16x32_f16 here) when the product is computed as Y^T = W * X^T
 // (rows = output features, columns = particles).  Because an MFMA's summation index may be permuted as long
 // as both operands agree, that same register group is directly the B operand of the next layer (k-step r of
 // tile t <-> feature feat(t,r,g)), so the whole [d -> 64 -> 64 -> 64 -> d] drift net runs out of registers with

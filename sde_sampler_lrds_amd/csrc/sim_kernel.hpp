@@ -1,12 +1,12 @@
-// The persistent whole-trajectory simulate kernel (FORM_LIN / FORM_EM) for gfx950.
+// The persistent whole-trajectory simulate kernel (FORM_LIN / FORM_EM / FORM_EUBO) for gfx950.
 //
 // One launch runs all N steps.  A wave keeps its 16 particles' state x[d] in registers for the whole
 // trajectory; HBM sees x once in and once out ((2d+1)*4 bytes per particle per TRAJECTORY).  Per step a
-// wave does: drift net (FP32 MFMA chain, weights in LDS), optional target score inside the control
+// wave does: drift net (split-f16 MFMA chain with fp32 accumulation, weights in LDS), optional target score inside the control
 // (ScoreCtrl/LerpCtrl), optional reference score (noised Gaussian / mixture; per-wave LDS table refilled by
 // LDS-DMA), noise (Philox in-register or injected), the integrator update and the log-RND accumulation
-// (two cross-lane adds per reduction).  No barrier inside the step loop: the four waves sharing a SIMD drift
-// apart so that one's MFMA phase overlaps the others' vector phases and memory waits.
+// (two cross-lane adds per reduction).  No barrier inside the step loop: the two waves sharing a SIMD interleave
+// freely (matrix and vector issue do not overlap on this part, so instruction count is what is optimised).
 #pragma once
 #include "sim_device.hpp"
 
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         }
       }
 
-      // ---- drift net up to the last hidden activation (FP32 MFMA chain) ----
+      // ---- drift net up to the last hidden activation (split-f16 MFMA chain) ----
       f32x4 hid[SD_HT];
       mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
       const HidSplit hs = split_hidden(hid);
