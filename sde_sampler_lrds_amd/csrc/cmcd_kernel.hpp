@@ -45,10 +45,12 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   split_tiles<NT>(x, xh, xl);
 
   f32x4 ts[NT];
-  if (s.target.kind != SDENG_DIST_LOGREG) {
+  if (s.target.kind == SDENG_DIST_PHI4) {
+    phi4_score<NT>(x, s.target, s.d, g, lane, ts);  // distr/phi_four.py:81-96 (pad features of x stay exactly 0 in this kernel)
+  } else if (s.target.kind != SDENG_DIST_LOGREG) {
     // diagonal Gaussian / mixture target (distr/gauss.py:97-107, 124-126): tables prepared by k_dist_tables
     gmm_score<NT>(x, s.target.tab, s.target.consts, 4, s.target.k, s.target.p0, g, ts);
-  } else {
+  } else if constexpr (NT <= 4) {
     // ---- logistic regression: prior part of the posterior + Xa^T r ----
     f32x4 tm[NT];
 #pragma unroll

@@ -16,6 +16,7 @@
 int sd_launch_cmcd_1(const CmcdArgs& a, int grid, hipStream_t s);
 int sd_launch_cmcd_2(const CmcdArgs& a, int grid, hipStream_t s);
 int sd_launch_cmcd_4(const CmcdArgs& a, int grid, hipStream_t s);
+int sd_launch_cmcd_8(const CmcdArgs& a, int grid, hipStream_t s);
 int sd_launch_logreg_images(const float* X, const float* y, int n, int dw, int NT, float* image, float* y_pad, hipStream_t s);
 int sd_launch_pack_square(const float* P, const float* loc, int d, int NT, float* out, float* loc_pad, hipStream_t s);
 
@@ -243,10 +244,10 @@ static int grid_for(int ntiles);
 // ControlledLangevinSDELoss.simulate (losses/oc.py:666-755): logistic-regression target, Gaussian prior
 static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s) {
   const int dpad = 16 * DT;
-  if (DT > 4) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: d <= 64 (got %d)", d->d);
   const bool logreg = d->target.kind == SDENG_DIST_LOGREG;
-  if (!logreg && d->target.kind != SDENG_DIST_GMM_DIAG && d->target.kind != SDENG_DIST_GAUSS_DIAG)
-    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: target must be LOGREG, GMM_DIAG or GAUSS_DIAG (kind %d)", d->target.kind);
+  if (!logreg && d->target.kind != SDENG_DIST_GMM_DIAG && d->target.kind != SDENG_DIST_GAUSS_DIAG && d->target.kind != SDENG_DIST_PHI4)
+    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: target must be LOGREG, GMM_DIAG, GAUSS_DIAG or PHI4 (kind %d)", d->target.kind);
+  if (logreg && DT > 4) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: logistic regression with d <= 64 (got %d)", d->d);
   const int n = logreg ? d->target.k : 0;  // data rows held in LDS
   if (logreg && n < 1) return fail(SDENG_E_INVALID, "CMCD kernel: logistic regression without data rows");
   if (static_cast<size_t>(cmcd_lds_floats(DT, n)) * sizeof(float) > 160 * 1024)
@@ -295,7 +296,7 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   a.target = target; a.prior = prior;
   c.s = a;
   if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
-  SD_HIP((DT == 1 ? sd_launch_cmcd_1 : (DT == 2 ? sd_launch_cmcd_2 : sd_launch_cmcd_4))(c, grid_for(a.ntiles), s));
+  SD_HIP((DT == 1 ? sd_launch_cmcd_1 : (DT == 2 ? sd_launch_cmcd_2 : (DT == 4 ? sd_launch_cmcd_4 : sd_launch_cmcd_8)))(c, grid_for(a.ntiles), s));
   if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
   TerminalArgs t;
   t.ref = target; t.target = target; t.use_ref = 0; t.use_target = 1;

@@ -102,10 +102,14 @@ def build(c, device):
             loss = oc.TimeReversalLoss(ctrl, ctrl, sde=sde, method="kl", inference_ctrl=None)
             kwargs = dict(initial_log_prob=prior.log_prob, train=False, compute_ito_int=True)
         out.update(loss=loss, args=(target.unnorm_log_prob,), kwargs=kwargs)
-    elif kind == "cmcd_gmm":
-        target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
-        prior = (IsotropicGauss(dim=d, scale=m["prior_scale"]) if m["prior_kind"] == "iso"
-                 else Gauss(dim=d, loc=c["prior_loc"], scale=c["prior_scale_vec"]))
+    elif kind in ("cmcd_gmm", "cmcd_phi4"):
+        if kind == "cmcd_phi4":
+            target = PhiFour(a=m["a"], b=m["b"], dim=d, beta=m["beta"])
+            prior = IsotropicGauss(dim=d, scale=m["prior_scale"])
+        else:
+            target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
+            prior = (IsotropicGauss(dim=d, scale=m["prior_scale"]) if m["prior_kind"] == "iso"
+                     else Gauss(dim=d, loc=c["prior_loc"], scale=c["prior_scale_vec"]))
         sde = ControlledLangevinSDE(target_score=target.score, prior_score=prior.score, diff_coeff=m["diff_coeff"],
                                     terminal_t=m["T"], clip_score=m["clip_langevin"])
         ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,

@@ -501,6 +501,27 @@ def case_cmcd_logreg(name, B, N, seed, dt):
     finish(name, meta, arrays, res, draws)
 
 
+def case_cmcd_phi4(name, d, B, N, seed):
+    """CMCD on the phi^4 lattice (conf/solver/cmcd.yaml with conf/target/phi_four.yaml), IsotropicGauss prior."""
+    torch.manual_seed(seed)
+    target = r_phi.PhiFour(a=0.1, b=0.0, dim=d, dim_phys=1, beta=20.0)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=0.5)
+    x0 = 0.5 * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    sde = r_sdes.ControlledLangevinSDE(target_score=target.score, prior_score=prior.score, diff_coeff=1.0, terminal_t=1.0, clip_score=1e5)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d), scale=0.02), score_model=score_time_embed(bias=0.001), target_score=target.score,
+                           detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
+    loss = r_oc.ControlledLangevinSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    ts = torch.linspace(0.0, 1.0, N + 1)
+    res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob,
+                                                         compute_weights=True, return_traj=True, use_ema=False))
+    (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob,
+                                                                   train=False))
+    meta = dict(kind="cmcd_phi4", d=d, B=B, N=N, seed=seed, diff_coeff=1.0, T=1.0, clip_langevin=1e5, clip_model=1e4, clip_score=1e4,
+                scale_score=1.0, a=0.1, b=0.0, beta=20.0, prior_scale=0.5)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], **pack_params("ctrl.", sd(ctrl)))
+    finish(name, meta, arrays, res, draws)
+
+
 def case_cmcd_gmm(name, d, K, B, N, seed, prior_kind="iso"):
     """CMCD on a Gaussian-mixture target (conf/solver/cmcd.yaml with conf/target/many_modes.yaml): IsotropicGauss(5) prior
     (benchmark_utils.py cmcd defaults) or a diagonal Gauss prior (update_prior with a variance vector, solver/oc.py:291-303)."""
@@ -670,6 +691,7 @@ CASES = {
     "cmcd_logreg_d61": lambda n: case_cmcd_logreg(n, B=64, N=16, seed=41, dt=1.0 / 256),
     "cmcd_gmm_iso_d16": lambda n: case_cmcd_gmm(n, d=16, K=4, B=64, N=32, seed=42, prior_kind="iso"),
     "cmcd_gmm_diag_d40": lambda n: case_cmcd_gmm(n, d=40, K=4, B=64, N=32, seed=43, prior_kind="diag"),
+    "cmcd_phi4_d100": lambda n: case_cmcd_phi4(n, d=100, B=16, N=256, seed=44),
     # DIS variants
     "dis_ei_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=51, kind="ei"),
     "dis_orig_lerp_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=64, seed=52, kind="orig"),

@@ -17,7 +17,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SIM_CASES = [
     "rds_ei_gmm_d128_k4", "rds_ei_gmm_d128_k4_n256", "rds_ei_gmm_d128_k16", "rds_ei_gmm_d8_k4",
     "rds_ddpm_gmm_d16_snr", "rds_em_gmm_d16", "rds_em_vp_default_d16", "rds_ei_vp_default_d16",
-    "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "dis_ei_d8",
+    "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "cmcd_phi4_d100", "dis_ei_d8",
     "dis_orig_lerp_d8",
 ]
 
@@ -135,9 +135,13 @@ def run_oracle(c: Case, noise=None, B=None):
                         clip_score=m["clip_score"], scale_score=m["scale_score"])
         out = orc.simulate_cmcd(ts, x0, ctrl, tgt.score, prior.score, m["diff_coeff"], m["T"], m["clip_langevin"],
                                 tgt.logp, prior.logp, noise)
-    elif kind == "cmcd_gmm":
-        tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
-        prior = orc.IsoGauss(m["d"], 0.0, m["prior_scale"]) if m["prior_kind"] == "iso" else orc.GaussDiag(c["prior_loc"], c["prior_scale_vec"])
+    elif kind in ("cmcd_gmm", "cmcd_phi4"):
+        if kind == "cmcd_phi4":
+            tgt = orc.PhiFour(m["a"], m["b"], m["d"], m["beta"])
+            prior = orc.IsoGauss(m["d"], 0.0, m["prior_scale"])
+        else:
+            tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+            prior = orc.IsoGauss(m["d"], 0.0, m["prior_scale"]) if m["prior_kind"] == "iso" else orc.GaussDiag(c["prior_loc"], c["prior_scale_vec"])
         ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score,
                         clip_score=m["clip_score"], scale_score=m["scale_score"])
         out = orc.simulate_cmcd(ts, x0, ctrl, tgt.score, prior.score, m["diff_coeff"], m["T"], m["clip_langevin"],

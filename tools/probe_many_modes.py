@@ -1,0 +1,11 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from sde_sampler_lrds_amd import _lib as L
+from sde_sampler_lrds_amd.experiments.baseline_configs import build_rds_gmm
+dev = torch.device("cuda:0")
+for K in (16, 64):
+    loss, ts, x0, args, _, info = build_rds_gmm(dev, 65536, 256, K=K)
+    ev = L.HipEvents(); loss.timing_events = ev
+    for rep in range(3):
+        x, rnd, _ = loss.simulate(ts, x0, *args); torch.cuda.synchronize(); ms = ev.elapsed_ms()
+    print(f"K={K}: kernel {ms:.2f} ms -> {65536*256/(ms*1e-3):.3e} p-steps/s finite {bool(torch.isfinite(rnd).all())} rnd mean {rnd.mean().item():.4f}")
