@@ -42,6 +42,10 @@ DTS, REFS, SCS, FORMS = (1, 2, 4, 8), (0, 1, 2, 3), (0, 1, 2), (0, 1)  # DTS: fe
 def sources():
     os.makedirs(GEN, exist_ok=True)
     srcs = [os.path.join(CSRC, "sdeng_api.hip"), os.path.join(CSRC, "prep_kernels.hip"), os.path.join(CSRC, "cmcd_inst.hip")]
+    for dt in (1, 2, 4):  # in-loop logistic-regression score (SC = 3): no reference, d <= 64, forward forms only
+        path = os.path.join(GEN, f"sim_{dt}_0_3.hip")
+        _write_if_changed(path, '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, 0, 3, {fm})\n" for fm in FORMS))
+        srcs.append(path)
     for dt in DTS:
         for rf in REFS:
             for sc in SCS:

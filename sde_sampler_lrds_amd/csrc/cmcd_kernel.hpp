@@ -12,20 +12,13 @@
 #include "sim_device.hpp"
 
 struct CmcdArgs {
-  SimArgs s;                // common fields (coef has N+1 rows: row k col 0 = ts[k])
-  const float* lr_image;    // global copy of the two LDS images: logits image, then grad image (sd_lr_*_floats)
-  const float* y_pad;       // [32 * row K-blocks] labels (0 on pad rows)
+  SimArgs s;                // common fields (coef has N+1 rows: row k col 0 = ts[k]); s.lr = logistic-regression target
   const float* prec_pack;   // packed prior precision (A operands of a [d x d] layer, split f16) or nullptr (isotropic)
   const float* prior_loc;   // [16*NT] prior mean (0-padded)
-  float inv_w_scale2, c_mean, inv_c_scale2;   // 1/weight_scale^2, intercept_mean, 1/intercept_scale^2
-  float p_lo, p_hi;         // sigmoid range with non-zero gradient (clip threshold and eps clamp)
   float iso_loc, inv_iso_var;   // isotropic prior
-  int n_rows;               // data rows n
 };
 
-__host__ __device__ inline int cmcd_lds_floats(int NT, int n_rows) {
-  return sd_lds_weight_floats(NT) + sd_lr_logit_floats(NT, n_rows) + sd_lr_grad_floats(NT, n_rows);
-}
+__host__ __device__ inline int cmcd_lds_floats(int NT, int n_rows) { return sd_lds_weight_floats(NT) + sd_lr_floats(NT, n_rows); }
 
 // (u, b) at (time index ki, state x): u = ctrl(t, x) (reparam.py:112-117), b = annealed drift (eq/sdes.py:101-110)
 template <int NT>
@@ -35,9 +28,6 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   const int g = lane >> 4;
   const SimArgs& s = a.s;
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-  const f16x8* im_logit = reinterpret_cast<const f16x8*>(lds + sd_lds_weight_floats(NT));
-  const f16x8* im_grad = reinterpret_cast<const f16x8*>(lds + sd_lds_weight_floats(NT) + sd_lr_logit_floats(NT, a.n_rows));
-  const int row_kb = sd_lr_row_kb(a.n_rows), row_tiles = sd_lr_row_tiles(a.n_rows);
   // the LDS images never change inside the step loop; without a barrier the compiler hoists their reads out of
   // it and keeps the A operands in (spilled) registers
   asm volatile("" ::: "memory");
@@ -51,51 +41,7 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
     // diagonal Gaussian / mixture target (distr/gauss.py:97-107, 124-126): tables prepared by k_dist_tables
     gmm_score<NT>(x, s.target.tab, s.target.consts, 4, s.target.k, s.target.p0, g, ts);
   } else if constexpr (NT <= 4) {
-    // ---- logistic regression: prior part of the posterior + Xa^T r ----
-    f32x4 tm[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = feat(t, r, g);
-        const float xv = x[t][r];
-        float v = -xv * a.inv_w_scale2;                                   // logistic_regression.py:72
-        v = (f == s.d - 1) ? -(xv - a.c_mean) * a.inv_c_scale2 : v;       // :74
-        ts[t][r] = (f < s.d) ? v : 0.0f;
-      }
-      tm[t] = zero;
-    }
-    for (int pr = 0; pr < row_kb; ++pr) {  // 32 data rows per pass = one K-block of the Xa^T r product
-      asm volatile("" ::: "memory");
-      f32x4 lg[2], lm[2];
-#pragma unroll
-      for (int o = 0; o < 2; ++o) {
-        lg[o] = zero;
-        lm[o] = zero;
-        const int tile = 2 * pr + o;
-        if (tile < row_tiles) {  // wave-uniform
-          f32x4 acc[1] = {zero}, mx[1] = {zero};
-          dense_pre<KB, 1>(xh, xl, acc, mx, im_logit + static_cast<size_t>(tile) * KB * 2 * 64, lane);
-          lg[o] = acc[0];
-          lm[o] = mx[0];
-        }
-        const f32x4 yv = load_tile4(a.y_pad, tile, g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          lg[o][r] = logreg_residual(__builtin_fmaf(lm[o][r], SD_LO_INV, lg[o][r]), yv[r], a.p_lo, a.p_hi);  // pad rows: Xa row = 0
-      }
-      f16x8 rh, rl;
-      split8(lg[0], lg[1], rh, rl);
-#pragma unroll
-      for (int to = 0; to < NT; ++to) {
-        const f16x8 ah = im_grad[((to * row_kb + pr) * 2 + 0) * 64 + lane];
-        const f16x8 al = im_grad[((to * row_kb + pr) * 2 + 1) * 64 + lane];
-        ts[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rh, ts[to], 0, 0, 0);
-        tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rl, tm[to], 0, 0, 0);
-        tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, rh, tm[to], 0, 0, 0);
-      }
-    }
-    fold_lo<NT>(ts, tm);
+    logreg_score<NT>(x, xh, xl, s.lr, s.d, lds + sd_lds_weight_floats(NT), lane, ts);
   }
 
   // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
@@ -174,8 +120,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
   {
     const int nw = sd_lds_weight_floats(NT);
     for (int i = tid; i < nw / 4; i += SD_THREADS) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(s.wpack)[i];
-    const int ni = sd_lr_logit_floats(NT, a.n_rows) + sd_lr_grad_floats(NT, a.n_rows);
-    for (int i = tid; i < ni / 4; i += SD_THREADS) reinterpret_cast<f32x4*>(lds + nw)[i] = reinterpret_cast<const f32x4*>(a.lr_image)[i];
+    const int ni = sd_lr_floats(NT, s.lr.n_rows);
+    for (int i = tid; i < ni / 4; i += SD_THREADS) reinterpret_cast<f32x4*>(lds + nw)[i] = reinterpret_cast<const f32x4*>(s.lr.image)[i];
   }
   __syncthreads();
   const float* bias = s.wpack + sd_off_bias(NT);
@@ -256,7 +202,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
 
 template <int NT>
 static int launch_cmcd(const CmcdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(cmcd_lds_floats(NT, a.n_rows)) * sizeof(float);
+  const size_t lds_bytes = static_cast<size_t>(cmcd_lds_floats(NT, a.s.lr.n_rows)) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);

@@ -21,7 +21,7 @@ int sd_launch_logreg_images(const float* X, const float* y, int n, int dw, int N
 int sd_launch_pack_square(const float* P, const float* loc, int d, int NT, float* out, float* loc_pad, hipStream_t s);
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };
-enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
+enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };
 
 typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
 #define SD_DECLARE_SIM(DT, REF, SC, FORM) int sd_launch_sim_##DT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s);
@@ -38,6 +38,10 @@ SD_EUBO_ROW(SD_DECLARE_SIM, 1)
 SD_EUBO_ROW(SD_DECLARE_SIM, 2)
 SD_EUBO_ROW(SD_DECLARE_SIM, 4)
 SD_EUBO_ROW(SD_DECLARE_SIM, 8)
+#define SD_LOGREG_ROW(M, DT) M(DT, 0, 3, 0) M(DT, 0, 3, 1)
+SD_LOGREG_ROW(SD_DECLARE_SIM, 1)
+SD_LOGREG_ROW(SD_DECLARE_SIM, 2)
+SD_LOGREG_ROW(SD_DECLARE_SIM, 4)
 #define SD_CTRL_ROW(M, DT) M(DT, 0) M(DT, 1) M(DT, 2)
 SD_CTRL_ROW(SD_DECLARE_CTRL, 1)
 SD_CTRL_ROW(SD_DECLARE_CTRL, 2)
@@ -53,6 +57,8 @@ static const sim_launch_fn kSimTable[4][4][3][2] = {
 // compute_eubo kernels: [tiles][reference kind - 1] for the reference-SDE losses (ClippedCtrl), [tiles][2 + score kind]
 // for DIS (no reference, ScoreCtrl)
 static const sim_launch_fn kEuboTable[4][5] = {{SD_EUBO_ROW(SD_ENTRY, 1)}, {SD_EUBO_ROW(SD_ENTRY, 2)}, {SD_EUBO_ROW(SD_ENTRY, 4)}, {SD_EUBO_ROW(SD_ENTRY, 8)}};
+// in-loop logistic-regression score (ScoreCtrl on a LOGREG target, no reference): [tiles 1,2,4][form LIN, EM]
+static const sim_launch_fn kLogregTable[3][2] = {{SD_LOGREG_ROW(SD_ENTRY, 1)}, {SD_LOGREG_ROW(SD_ENTRY, 2)}, {SD_LOGREG_ROW(SD_ENTRY, 4)}};
 #define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
 static const sim_launch_fn kCtrlTable[4][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}, {SD_CTRL_ROW(SD_CENTRY, 8)}};
 
@@ -107,9 +113,12 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.trash = o; o += align64(SD_THREADS * 4);
   L.logz = o; o += align64(5 * SD_LOGZ_MAX_BLOCKS);
   L.cmcd = o;
-  if (d->form == SDENG_FORM_CMCD) {
-    const int n = (d->target.kind == SDENG_DIST_LOGREG && d->target.k > 0) ? d->target.k : 0;
-    o += align64(sd_lr_logit_floats(DT, n) + sd_lr_grad_floats(DT, n)) + align64(32 * sd_lr_row_kb(n)) + align64(DT * sd_kb(DT) * 512) + align64(16 * DT);
+  {  // logistic-regression images (CMCD, or the in-loop score of a Score/LerpCtrl) and the CMCD prior's packed precision
+    const bool lr_used = d->target.kind == SDENG_DIST_LOGREG && d->target.k > 0 &&
+                         (d->form == SDENG_FORM_CMCD || d->net.ctrl_kind != SDENG_CTRL_CLIPPED);
+    const int n = lr_used ? d->target.k : 0;
+    o += align64(sd_lr_floats(DT, n)) + align64(32 * sd_lr_row_kb(n));
+    if (d->form == SDENG_FORM_CMCD) o += align64(DT * sd_kb(DT) * 512) + align64(16 * DT);
   }
   L.total = o;
   return true;
@@ -227,6 +236,7 @@ static int score_kind(const sdeng_desc* d, int& sc) {
     return fail(SDENG_E_UNSUPPORTED, "unknown ctrl_kind %d", d->net.ctrl_kind);
   if (d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_RINGS) sc = SC_GMM;  // rings: runtime branch of the d <= 16 kernel
   else if (d->target.kind == SDENG_DIST_PHI4) sc = SC_PHI4;
+  else if (d->target.kind == SDENG_DIST_LOGREG) sc = SC_LOGREG;
   else return fail(SDENG_E_UNSUPPORTED, "ScoreCtrl/LerpCtrl: no in-loop score kernel for target kind %d", d->target.kind);
   if (d->net.ctrl_kind == SDENG_CTRL_LERP && d->prior.kind != SDENG_DIST_ISO_GAUSS)
     return fail(SDENG_E_UNSUPPORTED, "LerpCtrl needs an IsotropicGauss prior (kind %d given)", d->prior.kind);
@@ -241,6 +251,23 @@ static int grid_for(int ntiles) {
 }
 
 static int grid_for(int ntiles);
+// logistic-regression target -> the two LDS images + the in-kernel constants (a.lr); returns the first float after them
+static int prepare_logreg(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s, float** next) {
+  const int n = d->target.k;
+  float* image = ws + L.cmcd;
+  float* y_pad = image + align64(sd_lr_floats(DT, n));
+  *next = y_pad + align64(32 * sd_lr_row_kb(n));
+  if (n < 1 || !d->target.loc || !d->target.scale) return fail(SDENG_E_INVALID, "LOGREG needs X, y and k >= 1 rows");
+  SD_HIP(sd_launch_logreg_images(d->target.loc, d->target.scale, n, d->d - 1, DT, image, y_pad, s));
+  a.lr.image = image; a.lr.y_pad = y_pad; a.lr.n_rows = n;
+  a.lr.inv_w_scale2 = 1.0f / (d->target.p0 * d->target.p0); a.lr.c_mean = d->target.p1; a.lr.inv_c_scale2 = 1.0f / (d->target.p2 * d->target.p2);
+  // sigmoid range with a gradient: inside clip(thr, 1 - thr) and inside the eps clamp of probs_to_logits
+  const float thr = d->target.p3, eps = 1.1920928955078125e-07f;
+  a.lr.p_lo = thr > eps ? thr : eps;
+  a.lr.p_hi = (1.0f - thr) < (1.0f - eps) ? (1.0f - thr) : (1.0f - eps);
+  return 0;
+}
+
 // ControlledLangevinSDELoss.simulate (losses/oc.py:666-755): logistic-regression target, Gaussian prior
 static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s) {
   const int dpad = 16 * DT;
@@ -268,20 +295,12 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   if (rc) return rc;
   CmcdArgs c;
   memset(&c, 0, sizeof(c));
-  float* image = ws + L.cmcd;
-  float* y_pad = image + align64(sd_lr_logit_floats(DT, n) + sd_lr_grad_floats(DT, n));
-  float* prec = y_pad + align64(32 * sd_lr_row_kb(n));
-  float* locp = prec + align64(DT * sd_kb(DT) * 512);
-  c.lr_image = image; c.y_pad = y_pad; c.n_rows = n;
+  float* prec = ws + L.cmcd;
   if (logreg) {
-    SD_HIP(sd_launch_logreg_images(d->target.loc, d->target.scale, n, d->d - 1, DT, image, y_pad, s));
-    c.inv_w_scale2 = 1.0f / (d->target.p0 * d->target.p0); c.c_mean = d->target.p1; c.inv_c_scale2 = 1.0f / (d->target.p2 * d->target.p2);
+    rc = prepare_logreg(d, L, ws, DT, a, s, &prec);
+    if (rc) return rc;
   }
-  if (logreg) {  // sigmoid range with a gradient: inside clip(thr, 1 - thr) and inside the eps clamp of probs_to_logits
-    const float thr = d->target.p3, eps = 1.1920928955078125e-07f;
-    c.p_lo = thr > eps ? thr : eps;
-    c.p_hi = (1.0f - thr) < (1.0f - eps) ? (1.0f - thr) : (1.0f - eps);
-  }
+  float* locp = prec + align64(DT * sd_kb(DT) * 512);
   if (d->prior.kind == SDENG_DIST_GAUSS_FULL) {
     SD_HIP(sd_launch_pack_square(d->prior.scale, d->prior.loc, d->d, DT, prec, locp, s));
     c.prec_pack = prec; c.prior_loc = locp;
@@ -391,6 +410,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     if ((rf == RF_NONE) == (sc == SC_NONE))
       return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels: a reference drift with a ClippedCtrl, or no reference with a Score/LerpCtrl "
                                        "(ref.kind %d, ctrl_kind %d)", d->ref.kind, d->net.ctrl_kind);
+    if (sc == SC_LOGREG) return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels: no logistic-regression control score");
     fn = kEuboTable[dt_index(DT)][rf != RF_NONE ? rf - 1 : 2 + sc];
     if (tr || tt) {  // cost at the data distribution: rnd0 = [log p_ref(x_in)] - log pi~(x_in)   (losses/oc.py:322, :536, :1003)
       SD_HIP(hipMemsetAsync(ws + L.rnd_init, 0, sizeof(float) * d->B, s));
@@ -398,6 +418,17 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
       SD_HIP(sd_launch_terminal(t, s));
       a.rnd_init = ws + L.rnd_init;
     }
+  } else if (sc == SC_LOGREG) {
+    // ScoreCtrl / LerpCtrl on a logistic-regression target (PIS, DDS, DIS on the Bayesian benchmarks): design matrix in LDS
+    if (rf != RF_NONE) return fail(SDENG_E_UNSUPPORTED, "in-loop logistic-regression score together with a reference drift");
+    if (DT > 4) return fail(SDENG_E_UNSUPPORTED, "in-loop logistic-regression score: d <= 64 (got %d)", d->d);
+    float* unused;
+    rc = prepare_logreg(d, L, ws, DT, a, s, &unused);
+    if (rc) return rc;
+    const size_t lds = (static_cast<size_t>(sd_lds_weight_floats(DT)) + sd_lr_floats(DT, a.lr.n_rows)) * sizeof(float);
+    if (lds > 160 * 1024)
+      return fail(SDENG_E_UNSUPPORTED, "drift net + design matrix (%d rows x %d) need %zu bytes of LDS, 163840 available", a.lr.n_rows, d->d, lds);
+    fn = kLogregTable[dt_index(DT)][d->form];
   } else {
     fn = kSimTable[dt_index(DT)][rf][sc][d->form];
   }

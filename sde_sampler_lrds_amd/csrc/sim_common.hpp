@@ -63,6 +63,15 @@ struct DistDev {
   float clip;
 };
 
+// logistic-regression target, in-kernel form (images built by k_logreg_images; see sim_device.hpp)
+struct LogregDev {
+  const float* image;       // global copy of the two LDS images: logits image, then grad image
+  const float* y_pad;       // [32 * row K-blocks] labels (0 on pad rows)
+  float inv_w_scale2, c_mean, inv_c_scale2;   // 1/weight_scale^2, intercept_mean, 1/intercept_scale^2
+  float p_lo, p_hi;         // sigmoid range with non-zero gradient (clip threshold and eps clamp)
+  int n_rows;               // data rows n (0: no logistic-regression target)
+};
+
 struct SimArgs {
   int form;
   unsigned flags;
@@ -90,4 +99,5 @@ struct SimArgs {
   float* trash;           // [SD_THREADS*4] dump slots for masked stores
   float cmcd_g, cmcd_clip;
   int ntiles;             // ceil(B / 16)
+  LogregDev lr;           // in-loop logistic-regression score (ScoreCtrl on a LOGREG target, CMCD)
 };

@@ -569,6 +569,7 @@ __host__ __device__ inline int sd_lr_row_tiles(int n) { return (n + 15) / 16; }
 __host__ __device__ inline int sd_lr_row_kb(int n) { return (n + 31) / 32; }
 __host__ __device__ inline int sd_lr_logit_floats(int NT, int n) { return sd_lr_row_tiles(n) * sd_kb(NT) * 512; }
 __host__ __device__ inline int sd_lr_grad_floats(int NT, int n) { return NT * sd_lr_row_kb(n) * 512; }
+__host__ __device__ inline int sd_lr_floats(int NT, int n) { return sd_lr_logit_floats(NT, n) + sd_lr_grad_floats(NT, n); }
 
 // Per-datum factor of the logistic-regression score.  The reference differentiates
 // sigmoid -> clip(thr) -> probs_to_logits(clamp eps) -> BCE-with-logits by autograd
@@ -581,3 +582,61 @@ SD_INLINE float logreg_residual(float logit, float y, float p_lo, float p_hi) {
   const float p = __builtin_amdgcn_rcpf(1.0f + e);
   return (p >= p_lo && p <= p_hi) ? (y - p) : 0.0f;
 }
+
+// score of the logistic-regression posterior for a 16-particle tile: prior part + Xa^T (y - sigmoid(Xa w)), both
+// products on the split-f16 matrix path with the A operands read from the two LDS images at `images`.
+template <int NT>
+SD_INLINE void logreg_score(const f32x4 (&x)[NT], const f16x8 (&xh)[(NT + 1) / 2], const f16x8 (&xl)[(NT + 1) / 2], const LogregDev& lr,
+                            int d, const float* images, int lane, f32x4 (&ts)[NT]) {
+  constexpr int KB = (NT + 1) / 2;
+  const int g = lane >> 4;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  const f16x8* im_logit = reinterpret_cast<const f16x8*>(images);
+  const f16x8* im_grad = reinterpret_cast<const f16x8*>(images + sd_lr_logit_floats(NT, lr.n_rows));
+  const int row_kb = sd_lr_row_kb(lr.n_rows), row_tiles = sd_lr_row_tiles(lr.n_rows);
+  f32x4 tm[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = feat(t, r, g);
+      const float xv = x[t][r];
+      float v = -xv * lr.inv_w_scale2;                                  // logistic_regression.py:72
+      v = (f == d - 1) ? -(xv - lr.c_mean) * lr.inv_c_scale2 : v;       // :74
+      ts[t][r] = (f < d) ? v : 0.0f;
+    }
+    tm[t] = zero;
+  }
+  for (int pr = 0; pr < row_kb; ++pr) {  // 32 data rows per pass = one K-block of the Xa^T r product
+    asm volatile("" ::: "memory");       // keeps the image reads inside the step loop (see cmcd_kernel.hpp)
+    f32x4 lg[2], lm[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      lg[o] = zero;
+      lm[o] = zero;
+      const int tile = 2 * pr + o;
+      if (tile < row_tiles) {  // wave-uniform
+        f32x4 acc[1] = {zero}, mx[1] = {zero};
+        dense_pre<KB, 1>(xh, xl, acc, mx, im_logit + static_cast<size_t>(tile) * KB * 2 * 64, lane);
+        lg[o] = acc[0];
+        lm[o] = mx[0];
+      }
+      const f32x4 yv = load_tile4(lr.y_pad, tile, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        lg[o][r] = logreg_residual(__builtin_fmaf(lm[o][r], SD_LO_INV, lg[o][r]), yv[r], lr.p_lo, lr.p_hi);  // pad rows: Xa row = 0
+    }
+    f16x8 rh, rl;
+    split8(lg[0], lg[1], rh, rl);
+#pragma unroll
+    for (int to = 0; to < NT; ++to) {
+      const f16x8 ah = im_grad[((to * row_kb + pr) * 2 + 0) * 64 + lane];
+      const f16x8 al = im_grad[((to * row_kb + pr) * 2 + 1) * 64 + lane];
+      ts[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rh, ts[to], 0, 0, 0);
+      tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, rl, tm[to], 0, 0, 0);
+      tm[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, rh, tm[to], 0, 0, 0);
+    }
+  }
+  fold_lo<NT>(ts, tm);
+}
+

@@ -11,7 +11,7 @@
 #include "sim_device.hpp"
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };  // GMM: K <= SD_KREG (responsibilities in registers)
-enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2 };
+enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };  // LOGREG: no reference table slots, d <= 64 (LDS)
 
 // score part of the generative control (added to clip(net)):
 //   ScoreCtrl (models/reparam.py:112-117):  scale*clip(score_pi(x)) * s_theta(t)
@@ -45,8 +45,13 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     const int n4 = sd_lds_weight_floats(NT) / 4;
     for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
+    if constexpr (SC == SC_LOGREG) {  // the two design-matrix images behind the weights
+      const int ni = sd_lr_floats(NT, a.lr.n_rows) / 4;
+      for (int i = tid; i < ni; i += SD_THREADS) dst[n4 + i] = reinterpret_cast<const f32x4*>(a.lr.image)[i];
+    }
   }
   __syncthreads();
+  static_assert(SC != SC_LOGREG || (REF == RF_NONE && NT <= 4), "in-loop logistic-regression score: no reference, d <= 64");
   const float* bias = a.wpack + sd_off_bias(NT);
   // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)
 #ifdef SD_DBG_NODMA
@@ -122,6 +127,12 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         else gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
       }
       if constexpr (SC == SC_PHI4) phi4_score<NT>(x, a.target, d_dyn, g, lane, ts);
+      if constexpr (SC == SC_LOGREG) {
+        asm volatile("" ::: "memory");
+        f16x8 xh[(NT + 1) / 2], xl[(NT + 1) / 2];
+        split_tiles<NT>(x, xh, xl);
+        logreg_score<NT>(x, xh, xl, a.lr, d_dyn, lds + sd_lds_weight_floats(NT), lane, ts);
+      }
       // reference drift (eq/sdes.py:265-279, 329-345): small mixtures keep only the K responsibilities and
       // assemble the score tile by tile in the tail; larger ones use the online-softmax accumulator
       const float* rtab = ref_lds ? my_tab : a.ref_tab + static_cast<size_t>(k) * tab_floats;
@@ -266,6 +277,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
       else gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
     }
     if constexpr (SC == SC_PHI4) phi4_score<NT>(x, a.target, a.d, g, lane, ts);
+    static_assert(SC != SC_LOGREG, "ctrl_forward is not instantiated for the in-loop logistic-regression score");
     float st = 1.0f;
     if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[0] : 1.0f;
 #pragma unroll
@@ -300,7 +312,8 @@ static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
 // host-side launcher, one per instantiation (defined in gen/sim_*.hip)
 template <int NT, int REF, int SC, int FORM, int PAR>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM));
+  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM)) +
+                           (SC == SC_LOGREG ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);

@@ -102,6 +102,25 @@ def build(c, device):
             loss = oc.TimeReversalLoss(ctrl, ctrl, sde=sde, method="kl", inference_ctrl=None)
             kwargs = dict(initial_log_prob=prior.log_prob, train=False, compute_ito_int=True)
         out.update(loss=loss, args=(target.unnorm_log_prob,), kwargs=kwargs)
+    elif kind in ("logreg_pis", "logreg_dds"):
+        target = LogisticRegression(c["X"], c["y"], intercept_mean=m["intercept_mean"], intercept_scale=m["intercept_scale"],
+                                    weight_scale=m["weight_scale"])
+        ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                         clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"])
+        ctrl.load_state_dict(c.params("ctrl."))
+        if kind == "logreg_pis":
+            sde = ScaledBM(diff_coeff=m["diff_coeff"], terminal_t=m["T"])
+            refd = Gauss(dim=d, loc=c["ref_loc"], scale=c["ref_scale"])
+            for mod in (sde, target, ctrl, refd):
+                mod.to(device)
+            loss = oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+            out.update(loss=loss, args=(target.unnorm_log_prob, refd.log_prob), kwargs={})
+        else:
+            prior = IsotropicGauss(dim=d, scale=m["sigma"])
+            for mod in (target, prior, ctrl):
+                mod.to(device)
+            loss = oc.ExponentialIntegratorSDELoss(ctrl, ctrl, sde=None, method="kl", alpha=m["alpha"], sigma=m["sigma"])
+            out.update(loss=loss, args=(target.unnorm_log_prob, prior.log_prob), kwargs=dict(compute_ito_int=True))
     elif kind in ("cmcd_gmm", "cmcd_phi4"):
         if kind == "cmcd_phi4":
             target = PhiFour(a=m["a"], b=m["b"], dim=d, beta=m["beta"])

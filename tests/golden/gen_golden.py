@@ -554,6 +554,59 @@ def case_cmcd_gmm(name, d, K, B, N, seed, prior_kind="iso"):
     finish(name, meta, arrays, res, draws)
 
 
+def case_logreg_ctrl(name, B, N, seed, solver):
+    """ScoreCtrl on the (synthetic-)sonar logistic regression with the non-CMCD solvers the reference benchmarks run on the
+    Bayesian targets: solver='pis' (EMReferenceSDELoss, ScaledBM, Delta prior) or 'dds' (ExponentialIntegratorSDELoss)."""
+    torch.manual_seed(seed)
+    X, y = synthetic_sonar()
+    target = SyntheticLogReg(X, y, intercept_mean=-2.5, intercept_scale=0.5, weight_scale=4.5)
+    d = target.dim
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d), scale=0.05), score_model=score_time_embed(bias=0.01), target_score=target.score,
+                           detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
+    if solver == "pis":
+        g, Tstar = 1.0, 1.0
+        sde = r_sdes.ScaledBM(diff_coeff=g, terminal_t=Tstar)
+        prior = r_delta.Delta(dim=d)
+        ref_distr = sde.marginal_distr(t=sde.terminal_t, x_init=prior.loc)
+        loss = r_oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+        ts = torch.linspace(0.0, Tstar, N + 1)
+        x0 = prior.sample((B,))
+        meta_extra = dict(diff_coeff=g, T=Tstar)
+        arr_extra = dict(ref_loc=ref_distr.loc, ref_scale=ref_distr.scale)
+        kw = dict()
+        ref_logp = ref_distr.log_prob
+    else:
+        sigma = 1.0
+        prior = r_gauss.IsotropicGauss(dim=d, scale=sigma)
+        loss = r_oc.ExponentialIntegratorSDELoss(ctrl, ctrl, sde=None, method="kl", alpha=1.0, sigma=sigma)
+        ts = r_get_timesteps(0.0, 3.2, dt=0.1, rescale_t="cosine")
+        x0 = sigma * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+        meta_extra = dict(alpha=1.0, sigma=sigma, dt=0.1, end=3.2)
+        arr_extra = dict()
+        kw = dict(compute_ito_int=True)
+        ref_logp = prior.log_prob
+    # Distribution.score needs autograd: no no_grad wrapper
+    orig = torch.randn_like
+    rep = Replay(seed)
+    torch.randn_like = rep
+    try:
+        res = loss.eval(ts, x0.clone(), target.unnorm_log_prob, ref_logp, compute_weights=True, return_traj=True, use_ema=False)
+    finally:
+        torch.randn_like = orig
+    draws = rep.k
+    rep = Replay(seed)
+    torch.randn_like = rep
+    try:
+        x_n, rnd, _ = loss.simulate(ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=ref_logp, **kw)
+    finally:
+        torch.randn_like = orig
+    meta = dict(kind="logreg_" + solver, d=d, B=B, N=len(ts) - 1, seed=seed, clip_model=1e4, clip_score=1e4, scale_score=1.0,
+                intercept_mean=-2.5, intercept_scale=0.5, weight_scale=4.5, **meta_extra)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd.detach(), xs_last2=res.xs[-2:].detach(), X=X, y=y, **arr_extra, **pack_params("ctrl.", sd(ctrl)))
+    res = res._replace(samples=res.samples.detach(), weights=res.weights.detach())
+    finish(name, meta, arrays, res, draws)
+
+
 def case_dis(name, d, K, B, N, seed, kind):
     """DIS: kind='ei' -> DiscreteTimeReversalLossEI with ScoreCtrl; kind='orig' -> TimeReversalLoss with
     LerpCtrl (conf/solver/dis.yaml, conf/model/lerp.yaml, solver/oc.py:185-261)."""
@@ -692,6 +745,8 @@ CASES = {
     "cmcd_gmm_iso_d16": lambda n: case_cmcd_gmm(n, d=16, K=4, B=64, N=32, seed=42, prior_kind="iso"),
     "cmcd_gmm_diag_d40": lambda n: case_cmcd_gmm(n, d=40, K=4, B=64, N=32, seed=43, prior_kind="diag"),
     "cmcd_phi4_d100": lambda n: case_cmcd_phi4(n, d=100, B=16, N=256, seed=44),
+    "pis_logreg_d61": lambda n: case_logreg_ctrl(n, B=32, N=32, seed=45, solver="pis"),
+    "dds_logreg_d61": lambda n: case_logreg_ctrl(n, B=32, N=32, seed=46, solver="dds"),
     # DIS variants
     "dis_ei_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=51, kind="ei"),
     "dis_orig_lerp_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=64, seed=52, kind="orig"),

@@ -17,7 +17,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SIM_CASES = [
     "rds_ei_gmm_d128_k4", "rds_ei_gmm_d128_k4_n256", "rds_ei_gmm_d128_k16", "rds_ei_gmm_d8_k4",
     "rds_ddpm_gmm_d16_snr", "rds_em_gmm_d16", "rds_em_vp_default_d16", "rds_ei_vp_default_d16",
-    "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "cmcd_phi4_d100", "dis_ei_d8",
+    "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "cmcd_phi4_d100", "pis_logreg_d61", "dds_logreg_d61", "dis_ei_d8",
     "dis_orig_lerp_d8",
 ]
 
@@ -135,6 +135,17 @@ def run_oracle(c: Case, noise=None, B=None):
                         clip_score=m["clip_score"], scale_score=m["scale_score"])
         out = orc.simulate_cmcd(ts, x0, ctrl, tgt.score, prior.score, m["diff_coeff"], m["T"], m["clip_langevin"],
                                 tgt.logp, prior.logp, noise)
+    elif kind in ("logreg_pis", "logreg_dds"):
+        tgt = orc.LogReg(c["X"], c["y"], m["weight_scale"], m["intercept_mean"], m["intercept_scale"])
+        ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score, clip_score=m["clip_score"],
+                        scale_score=m["scale_score"])
+        if kind == "logreg_pis":
+            sde = orc.ScaledBM(m["diff_coeff"], m["T"])
+            refd = orc.GaussDiag(c["ref_loc"], c["ref_scale"])
+            out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, None, noise)
+        else:
+            prior = orc.IsoGauss(m["d"], 0.0, m["sigma"])
+            out = orc.simulate_dds(ts, x0, ctrl, m["alpha"], m["sigma"], tgt.logp, prior.logp, noise)
     elif kind in ("cmcd_gmm", "cmcd_phi4"):
         if kind == "cmcd_phi4":
             tgt = orc.PhiFour(m["a"], m["b"], m["d"], m["beta"])

@@ -124,7 +124,7 @@ def test_cfg4_cmcd_logreg_shard_65536x256(gpu):
 # small launch of just that block (one wave per SIMD: the regime the fixtures pin against the reference).
 BIG = [("rds_ei_gmm_d128_k16", 32768), ("rds_ei_gmm_d8_k4", 65536), ("rds_ddpm_gmm_d16_snr", 65536), ("rds_em_gmm_d16", 65536),
        ("rds_ei_vp_default_d16", 65536), ("rds_ei_pbm_default_d16", 65536), ("dds_two_modes_d2", 65536), ("dds_rings_d2", 65536),
-       ("dis_ei_d8", 65536), ("dis_orig_lerp_d8", 65536), ("pis_em_phi4_d100", 32768), ("cmcd_logreg_d61", 32768), ("cmcd_gmm_iso_d16", 65536), ("cmcd_gmm_diag_d40", 32768), ("cmcd_phi4_d100", 32768)]
+       ("dis_ei_d8", 65536), ("dis_orig_lerp_d8", 65536), ("pis_em_phi4_d100", 32768), ("cmcd_logreg_d61", 32768), ("cmcd_gmm_iso_d16", 65536), ("cmcd_gmm_diag_d40", 32768), ("cmcd_phi4_d100", 32768), ("pis_logreg_d61", 32768), ("dds_logreg_d61", 32768)]
 
 
 @pytest.mark.gpu
