@@ -42,6 +42,11 @@ DTS, REFS, SCS, FORMS = (1, 2, 4, 8), (0, 1, 2, 3), (0, 1, 2), (0, 1)  # DTS: fe
 def sources():
     os.makedirs(GEN, exist_ok=True)
     srcs = [os.path.join(CSRC, "sdeng_api.hip"), os.path.join(CSRC, "prep_kernels.hip"), os.path.join(CSRC, "cmcd_inst.hip")]
+    for dt in DTS:  # CMCD kernels (3 target kinds each)
+        path = os.path.join(GEN, f"cmcd_{dt}.hip")
+        _write_if_changed(path, '#include "../cmcd_kernel.hpp"\n'
+                                f"int sd_launch_cmcd_{dt}(const CmcdArgs& a, int grid, hipStream_t s) {{ return launch_cmcd<{dt}>(a, grid, s); }}\n")
+        srcs.append(path)
     for dt in (1, 2, 4):  # in-loop logistic-regression score (SC = 3): no reference, d <= 64, forward forms only
         path = os.path.join(GEN, f"sim_{dt}_0_3.hip")
         _write_if_changed(path, '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, 0, 3, {fm})\n" for fm in FORMS))

@@ -1,8 +1,5 @@
 #include "cmcd_kernel.hpp"
-int sd_launch_cmcd_1(const CmcdArgs& a, int grid, hipStream_t s) { return launch_cmcd<1>(a, grid, s); }
-int sd_launch_cmcd_2(const CmcdArgs& a, int grid, hipStream_t s) { return launch_cmcd<2>(a, grid, s); }
-int sd_launch_cmcd_4(const CmcdArgs& a, int grid, hipStream_t s) { return launch_cmcd<4>(a, grid, s); }
-int sd_launch_cmcd_8(const CmcdArgs& a, int grid, hipStream_t s) { return launch_cmcd<8>(a, grid, s); }
+// (the k_simulate_cmcd instantiations live in gen/cmcd_<tiles>.hip, one translation unit per tile count)
 
 // one 16-bit half of a packed split-f16 A-operand image (layout of k_pack_mlp): block (to, kb), part, lane, j
 //   -> (o, i) = (16 to + (lane & 15), 16 (2 kb + j/4) + 4 (lane >> 4) + j%4)

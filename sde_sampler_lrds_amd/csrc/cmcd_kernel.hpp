@@ -21,7 +21,9 @@ struct CmcdArgs {
 __host__ __device__ inline int cmcd_lds_floats(int NT, int n_rows) { return sd_lds_weight_floats(NT) + sd_lr_floats(NT, n_rows); }
 
 // (u, b) at (time index ki, state x): u = ctrl(t, x) (reparam.py:112-117), b = annealed drift (eq/sdes.py:101-110)
-template <int NT>
+enum { CT_LOGREG = 0, CT_GMM = 1, CT_PHI4 = 2 };  // target kind is a template parameter: one score body per kernel
+
+template <int NT, int TGT>
 SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float w_t, float w_1mt, const float* lds,
                          const float* bias, int lane, f32x4 (&u)[NT], f32x4 (&b)[NT]) {
   constexpr int KB = (NT + 1) / 2;
@@ -35,12 +37,13 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   split_tiles<NT>(x, xh, xl);
 
   f32x4 ts[NT];
-  if (s.target.kind == SDENG_DIST_PHI4) {
+  if constexpr (TGT == CT_PHI4) {
     phi4_score<NT>(x, s.target, s.d, g, lane, ts);  // distr/phi_four.py:81-96 (pad features of x stay exactly 0 in this kernel)
-  } else if (s.target.kind != SDENG_DIST_LOGREG) {
+  } else if constexpr (TGT == CT_GMM) {
     // diagonal Gaussian / mixture target (distr/gauss.py:97-107, 124-126): tables prepared by k_dist_tables
     gmm_score<NT>(x, s.target.tab, s.target.consts, 4, s.target.k, s.target.p0, g, ts);
-  } else if constexpr (NT <= 4) {
+  } else {
+    static_assert(TGT != CT_LOGREG || NT <= 4, "logistic regression: d <= 64 (design matrix in LDS)");
     logreg_score<NT>(x, xh, xl, s.lr, s.d, lds + sd_lds_weight_floats(NT), lane, ts);
   }
 
@@ -110,7 +113,7 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   }
 }
 
-template <int NT>
+template <int NT, int TGT>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(const CmcdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SimArgs& s = a.s;
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     f32x4 w_s[NT];
     if (s.N > 0) {
       f32x4 u0[NT], b0[NT];
-      cmcd_eval<NT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, lane, u0, b0);
+      cmcd_eval<NT, TGT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, lane, u0, b0);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
       float c2 = 0.0f, cdb = 0.0f;
       {
         f32x4 u_t[NT], b_t[NT];
-        cmcd_eval<NT>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t);
+        cmcd_eval<NT, TGT>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -200,12 +203,19 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
   }
 }
 
-template <int NT>
-static int launch_cmcd(const CmcdArgs& a, int grid, hipStream_t stream) {
+template <int NT, int TGT>
+static int launch_cmcd_t(const CmcdArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(cmcd_lds_floats(NT, a.s.lr.n_rows)) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT, TGT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_simulate_cmcd<NT>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_simulate_cmcd<NT, TGT>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
+}
+template <int NT>
+static int launch_cmcd(const CmcdArgs& a, int grid, hipStream_t stream) {
+  if (a.s.target.kind == SDENG_DIST_PHI4) return launch_cmcd_t<NT, CT_PHI4>(a, grid, stream);
+  if (a.s.target.kind != SDENG_DIST_LOGREG) return launch_cmcd_t<NT, CT_GMM>(a, grid, stream);
+  if constexpr (NT <= 4) return launch_cmcd_t<NT, CT_LOGREG>(a, grid, stream);
+  return static_cast<int>(hipErrorInvalidValue);
 }
