@@ -445,6 +445,18 @@ class TimeReversalLoss(_InitialLogProbLoss):
                               form=L.FORM_EM, flags=L.FLAG_ITO if compute_ito_int else 0, use_ema=False,
                               return_traj=return_traj, noise=noise, coef_kw=dict(train=train, dim=x.shape[-1], lerp=lerp))
 
+    def __call__(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None):
+        """[TRAINING] losses/oc.py:1240-1272, log-variance methods, no inference control: cost <u, u.detach() - u/2> dt + <u, db>."""
+        if self.method in ("kl", "kl_ito"):
+            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
+        lerp = type(self.generative_ctrl).__name__ == "LerpCtrl"
+
+        def sim(xx, z):
+            return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=None, train=True,
+                                 compute_ito_int=True, change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+        return self._lv_loss(ts, x, sim, lambda xn: -terminal_unnorm_log_prob(xn), lin=False, rnd0=initial_log_prob,
+                             coef_kw=dict(train=True, dim=x.shape[-1], lerp=lerp))
+
 
 class ExponentialIntegratorSDELoss(BaseOCLoss):
     """losses/oc.py:1310-1467 (DDS)."""

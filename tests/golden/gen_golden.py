@@ -292,6 +292,23 @@ def case_train_lv_dis(name, d, K, B, N, seed):
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
 
 
+def case_train_lv_dis_orig(name, d, K, B, N, seed):
+    """TimeReversalLoss.__call__ (losses/oc.py:1240-1272), method='lv', LerpCtrl, no inference control (dis_orig)."""
+    torch.manual_seed(seed)
+    sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=1.0)
+    ctrl = r_rep.LerpCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0), target_score=target.score,
+                          detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0, sde=sde, prior_score=prior.score)
+    loss = r_oc.TimeReversalLoss(ctrl, ctrl, sde=sde, method="lv", inference_ctrl=None)
+    ts = r_get_timesteps(0.0, 1.0, steps=N)
+    x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    meta = dict(kind="train_lv_dis_orig", d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0, clip_model=1e4,
+                clip_score=1e4, scale_score=1.0)
+    arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
+    _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
+
+
 def case_train_lv_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0):
     """ExponentialIntegratorSDELoss.__call__ (losses/oc.py:1399-1428), method='lv', TwoModes target."""
     torch.manual_seed(seed)
@@ -734,6 +751,7 @@ CASES = {
     "train_lv_em_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=72, integrator="em"),
     "train_lv_dis_ei_d8": lambda n: case_train_lv_dis(n, d=8, K=4, B=64, N=32, seed=73),
     "train_lv_dds_d2": lambda n: case_train_lv_dds(n, d=2, B=128, seed=74),
+    "train_lv_dis_orig_d8": lambda n: case_train_lv_dis_orig(n, d=8, K=4, B=64, N=64, seed=76),
     "train_lv_pis_phi4_d100": lambda n: case_train_lv_pis(n, d=100, B=32, N=16, seed=75, dt=5.0 / 512),
     # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
     "pis_em_phi4_d100": lambda n: case_pis_phi4(n, d=100, B=64, N=32, seed=21, dt=5.0 / 512),
