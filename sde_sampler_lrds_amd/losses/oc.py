@@ -9,8 +9,7 @@ What is on the HIP path: the eval / sampling direction (``change_sde_ctrl=False`
 ``Trainable.evaluate`` times as ``eval/sample_time`` (solver/oc.py:148-158).  ``compute_eubo`` (the noising loops of
 SURVEY.md 8f-2) is a HIP launch too for the RDS losses and DiscreteTimeReversalLossEI.  The training direction (``__call__``,
 8f-1) is built for the log-variance methods (``_lv_loss``: HIP step loop + one batched autograd pass of the control); KL
-training, the CMCD / TimeReversal losses' training and the CMCD ``compute_eubo`` raise instead of silently running a PyTorch
-loop.
+training and the CMCD ``compute_eubo`` raise instead of silently running a PyTorch loop.
 
 Extra, engine-only knobs (keyword-only, default to the reference behaviour):
   * ``noise=[N,B,d]`` injects the normals (replays the reference's ``randn_like`` stream, parity mode);
@@ -382,6 +381,53 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
         desc.coef = coef.data_ptr()
         x_out, rnd, xs = E.run(desc, x, keep, return_traj=return_traj, noise=noise, events=self.timing_events)
         return x_out, rnd, xs
+
+
+    def __call__(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None):
+        """[TRAINING] losses/oc.py:830-857, log-variance methods.  The trajectory is driven by the detached control
+        (:704-705, :722), so it is the eval trajectory: one HIP launch (trajectory and noise kept).  The target / prior
+        scores along it come from the HIP distribution kernels (no graph needed: the states are constants), and one batched
+        autograd pass of the control over the (N+1)*B (time, state) pairs rebuilds (:736-742)
+            cost_k = (b_k + b'_k)/g + u_k - u_{k+1},   rnd = rnd0 + sum_k 0.5|cost_k|^2 dt + <cost_k, u_k.detach() - u_k> dt + <cost_k, db_k> - log pi~(x_N)
+        with b_k = drift(t_k, x_k), b'_k = drift(t_{k+1}, x_{k+1})."""
+        if self.method in ("kl", "kl_ito"):
+            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
+        if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
+            raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control: not built")
+        if self.traj_per_sample != 1:
+            x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
+        N, (B, d) = ts.numel() - 1, x.shape
+        seed_c = (int(self.seed) + 0x9E3779B97F4A7C15 * self.train_calls) & 0xFFFFFFFFFFFFFFFF
+        self.train_calls += 1
+        z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)
+        target = getattr(self.sde.target_score, "__self__", None)
+        prior = getattr(self.sde.prior_score, "__self__", None)
+        g, T = float(self.sde.diff_coeff), float(self.sde.terminal_t)
+        with torch.no_grad():
+            x_n, _, xs = self.simulate(ts, x, terminal_unnorm_log_prob, initial_log_prob=initial_log_prob, train=False,
+                                       return_traj=True, use_ema=False, noise=z)
+            flat = xs.reshape((N + 1) * B, d)
+            _, s_tgt = E.dist_eval(target, flat, want_logp=False)
+            _, s_pri = E.dist_eval(prior, flat, want_logp=False)
+            s_tgt, s_pri = s_tgt.view(N + 1, B, d), s_pri.view(N + 1, B, d)
+
+            def drift(k_time, k_state):  # eq/sdes.py:101-110 at (ts[k_time], xs[k_state])
+                w = (ts[k_time] / T).view(-1, 1, 1)
+                out = (s_tgt[k_state] * w + s_pri[k_state] * (1.0 - w)) * (0.5 * g ** 2)
+                return out if not self.sde.clip_score else out.clip(-float(self.sde.clip_score), float(self.sde.clip_score))
+            idx = torch.arange(N, device=x.device)
+            b_s, b_t = drift(idx, idx), drift(idx + 1, idx + 1)
+            const = -terminal_unnorm_log_prob(x_n)
+            if initial_log_prob is not None:
+                const = const + initial_log_prob(x).view((-1, 1))
+        t_rows = ts.to(x.device).repeat_interleave(B).view(-1, 1)
+        u = self.generative_ctrl(t_rows, flat).view(N + 1, B, d)
+        dt = (ts[1:] - ts[:-1]).view(N, 1, 1)
+        db = dt.sqrt() * z
+        cost = (b_s + b_t) / g + u[:-1] - u[1:]
+        rnd = (0.5 * (cost ** 2).sum(-1) * dt.view(N, 1) + (cost * (u[:-1].detach() - u[:-1])).sum(-1) * dt.view(N, 1)
+               + (cost * db).sum(-1)).sum(0).view(B, 1) + const
+        return self.compute_loss(rnd, samples=x_n)
 
 
 class DiscreteTimeReversalLossEI(_InitialLogProbLoss):

@@ -9,11 +9,11 @@ from tests import build_cases as bc
 from tests import golden_cases as gc
 
 
-KINDS = {"train_lv": "rds_gmm", "train_lv_dis": "dis_ei", "train_lv_dis_orig": "dis_orig", "train_lv_dds": "dds", "train_lv_pis": "pis_phi4"}  # objects as in the simulate cases
+KINDS = {"train_lv": "rds_gmm", "train_lv_dis": "dis_ei", "train_lv_dis_orig": "dis_orig", "train_lv_dds": "dds", "train_lv_pis": "pis_phi4", "train_lv_cmcd": "cmcd_gmm"}  # objects as in the simulate cases
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["train_lv_ei_gmm_d16", "train_lv_em_gmm_d16", "train_lv_dis_ei_d8", "train_lv_dds_d2", "train_lv_pis_phi4_d100", "train_lv_dis_orig_d8"])
+@pytest.mark.parametrize("name", ["train_lv_ei_gmm_d16", "train_lv_em_gmm_d16", "train_lv_dis_ei_d8", "train_lv_dds_d2", "train_lv_pis_phi4_d100", "train_lv_dis_orig_d8", "train_lv_cmcd_gmm_d16"])
 def test_lv_training_loss_and_gradients_match_reference(gpu, name):
     c = gc.load(name)
     c.meta["kind"] = KINDS[c.meta["kind"]]
