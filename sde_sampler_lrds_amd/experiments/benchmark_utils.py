@@ -126,3 +126,27 @@ def make_model(solver_type, ref_type, loss_type, integrator_type, model_type, ti
         model.train_timesteps = partial(get_timesteps, **model.train_timesteps.keywords, sde=model.sde)
         model.eval_timesteps = model.train_timesteps
     return model
+
+
+def fit_gmm(n_components, dataset, means_init=None, em_type="diag", max_iter=1000):
+    """experiments/benchmark_utils.py:336-361: fit the mixture that becomes the learned reference of (L)RDS
+    (``model.change_reference_type('gmm', weights=..., means=..., variances=...)``).  Host-side data preparation with
+    scikit-learn, like upstream; the engine's reference kernels take diagonal mixtures (``em_type='diag'``)."""
+    from sklearn.mixture import GaussianMixture
+    if em_type != "diag":
+        raise NotImplementedError("full-covariance references have no HIP kernel (distr/gauss.py:110-121 score_mog_full)")
+    data = dataset.reshape(-1, dataset.shape[-1]).cpu().numpy()
+    last = None
+    for reg_covar in [1e-6, 5e-5, 1e-5, 5e-4, 1e-4, 5e-3, 1e-3, 5e-2, 1e-2]:
+        try:
+            gmm = GaussianMixture(n_components=n_components, covariance_type=em_type, reg_covar=reg_covar, max_iter=max_iter,
+                                  means_init=means_init.cpu().numpy() if means_init is not None else None).fit(data)
+            weights = torch.from_numpy(gmm.weights_).float()
+            means = torch.from_numpy(gmm.means_).float()
+            variances = torch.from_numpy(gmm.covariances_).float()
+            if bool(torch.isfinite(variances).all()) and bool((variances > 0).all()):
+                return weights, means, variances
+        except Exception as e:  # noqa: BLE001  (upstream retries with the next regulariser on any failure)
+            last = e
+    raise ValueError(f"Couldn't fit a GMM on this dataset. ({last})")
+

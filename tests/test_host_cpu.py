@@ -126,3 +126,13 @@ def test_mirror_modules_match_oracle_on_cpu():
     with torch.no_grad():
         assert gc.rel_err(ctrl(t, c["x_mid"]), c["u_mid"]) < 1e-6
     assert gc.rel_err(o(t, c["x_mid"]), c["u_mid"]) < 1e-6
+
+
+def test_fit_gmm_gives_a_diagonal_reference():
+    """experiments/benchmark_utils.py:336-361 mirror: the learned-reference preparation step of LRDS."""
+    from sde_sampler_lrds_amd.experiments.benchmark_utils import fit_gmm
+    g = torch.Generator().manual_seed(0)
+    data = torch.cat([torch.randn(400, 3, generator=g) + 3.0, torch.randn(400, 3, generator=g) - 3.0])
+    w, m, v = fit_gmm(2, data)
+    assert w.shape == (2,) and m.shape == (2, 3) and v.shape == (2, 3)
+    assert abs(float(w.sum()) - 1.0) < 1e-5 and float(m.abs().mean()) > 2.0
