@@ -51,12 +51,16 @@ def dist_desc(obj, device, keep, clip=None) -> L.Dist:
         return ds
     n = _name(obj)
     if n == "IsotropicGauss":
-        loc, scale = obj.loc[0, 0].detach().float().cpu(), obj.scale[0, 0].detach().float().cpu()
-        var = scale ** 2
+        # the four scalars are read back from the device once per parameter version (a read-back synchronises the stream)
+        key = (obj.loc._version, obj.scale._version, obj.loc.data_ptr(), obj.scale.data_ptr())
+        hit = getattr(obj, "_sdeng_scalars", None)
+        if hit is None or hit[0] != key:
+            loc, scale = obj.loc[0, 0].detach().float().cpu(), obj.scale[0, 0].detach().float().cpu()
+            var = scale ** 2
+            hit = (key, (float(loc), float(scale), float(-0.5 * obj.dim * (2.0 * math.pi * var).log()), float(var)))  # distr/gauss.py:759
+            obj._sdeng_scalars = hit
         ds.kind = L.DIST_ISO_GAUSS
-        ds.p0, ds.p1 = float(loc), float(scale)
-        ds.p2 = float(-0.5 * obj.dim * (2.0 * math.pi * var).log())  # distr/gauss.py:759
-        ds.p3 = float(var)
+        ds.p0, ds.p1, ds.p2, ds.p3 = hit[1]
         return ds
     if n in ("GMM", "TwoModes", "ManyModes", "BracketTwoModes", "Gauss", "Delta"):
         if getattr(obj, "mixture_weights", None) is None:
@@ -78,13 +82,17 @@ def dist_desc(obj, device, keep, clip=None) -> L.Dist:
         ds.p0, ds.p1, ds.p2 = float(obj.a), float(obj.b), float(obj.beta)
         return ds
     if n == "GaussFull":
-        cov = obj.cov.detach().float().cpu()
-        tril = torch.linalg.cholesky(cov)
+        key = (obj.cov._version, obj.cov.data_ptr(), str(device))
+        hit = getattr(obj, "_sdeng_chol", None)
+        if hit is None or hit[0] != key:  # Cholesky factor, its inverse and log-determinant once per parameter version
+            tril = torch.linalg.cholesky(obj.cov.detach().float().cpu())
+            hit = (key, torch.linalg.inv(tril).to(device), float(tril.diagonal().log().sum()))
+            obj._sdeng_chol = hit
         ds.kind = L.DIST_GAUSS_FULL
         ds.loc = _dev_f32(obj.loc, device, keep)
         ds.scale = _dev_f32(obj.prec, device, keep)
-        ds.w = _dev_f32(torch.linalg.inv(tril), device, keep)
-        ds.p0 = float(tril.diagonal().log().sum())
+        ds.w = _dev_f32(hit[1], device, keep)
+        ds.p0 = hit[2]
         return ds
     if n in ("LogisticRegression", "SyntheticLogReg"):
         ds.kind = L.DIST_LOGREG

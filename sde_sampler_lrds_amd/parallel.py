@@ -58,7 +58,9 @@ def global_results_async(rnd: torch.Tensor, dist=None) -> PendingResults:
     """Enqueue the estimators over ALL ranks' particles from this rank's ``rnd`` shard [B,1] (device tensor)."""
     from . import engine
     stats, _ = engine.logz_stats(rnd, want_weights=False)
-    count = torch.tensor([float(rnd.shape[0])], device=rnd.device)
+    # torch.full, not torch.tensor([...], device=...): a host->device copy of pageable memory synchronises the stream and
+    # would stop the caller from keeping several passes in flight
+    count = torch.full((1,), float(rnd.shape[0]), dtype=stats.dtype, device=rnd.device)
     payload = torch.cat([stats, count])
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return PendingResults(payload.view(1, 9))
