@@ -91,6 +91,36 @@ def test_coef_table_matches_reference_scalars():
         assert tabp[k, 1] == tsp[k + 1] / tsp[k]
 
 
+def test_eubo_coef_tables_follow_the_noising_loops():
+    """compute_eubo coefficient rows (iteration order, times running backwards) against the oracle's scalars
+    (losses/oc.py:325-358 EM, :539-564 EI)."""
+    from oracle import sde_oracle as orc
+    from sde_sampler_lrds_amd.eq.sdes import VP
+    ts = torch.linspace(0.0, 1.0, 13)
+    N, T = 12, ts[-1]
+    o = orc.VP(0.1, 10.0, 1.0, 1.0)
+    ei = E.coef_table("eubo_ei", ts, VP(0.1, 10.0, 1.0, terminal_t=1.0), with_ref=True)
+    em = E.coef_table("eubo_em", ts, VP(0.1, 10.0, 1.0, terminal_t=1.0), with_ref=True, rescale=True)
+    for k in range(N):
+        s, t = ts[N - 1 - k], ts[N - k]
+        mean_f, var_f = o.transition_params(T - t, T - s)
+        assert ei[k, 0] == T - s and ei[k, 1] == mean_f and ei[k, 3] == var_f.sqrt() and ei[k, 2] == 1.0 and ei[k, 6] == 0.0
+        assert ei[k, 4] == o.omega(s, t) and ei[k, 5] == torch.sqrt(o.omega(s, t))
+        g, dt = o.diff(T - s), t - s
+        assert em[k, 1] == mean_f and em[k, 3] == var_f.sqrt() and em[k, 2] == 1.0 / g
+        assert em[k, 4] == dt * g ** 2 and em[k, 5] == var_f.sqrt() / mean_f
+        assert em[k, 6] == 1.0 / mean_f - 1.0 + o.drift_coeff(T - s) * dt
+        assert ei[k, 9] == o.s(T - s)
+
+
+def test_training_direction_refuses_kl_without_a_gpu_path():
+    c = gc.load("rds_ei_gmm_d8_k4")
+    b = bc.build(c, "cpu")
+    b["loss"].method = "kl"
+    with pytest.raises(E.UnsupportedByEngine, match="KL training"):
+        b["loss"](b["ts"], b["x0"], *b["args"])
+
+
 def test_no_cpu_execution_path():
     c = gc.load("rds_ei_gmm_d8_k4")
     b = bc.build(c, "cpu")
