@@ -58,6 +58,9 @@ extern "C" {
 #define SDENG_FORM_EM 1
 #define SDENG_FORM_CMCD 2
 #define SDENG_FORM_EUBO 3
+#define SDENG_FORM_CMCD_EUBO 4 /* ControlledLangevinSDELoss.compute_eubo losses/oc.py:757-828: the CMCD loop run from target samples
+                                  with -u; coef rows in iteration order ([0] = ts[N-k], [2],[3] = dt, sqrt(dt) of iteration k,
+                                  [4..7] = annealing weights of that time); rnd0 = -log pi~(x_in), + log p_prior(x_out) at the end */
 
 /* Per-step coefficient table: coef[N][SDENG_NCOEF], filled by the host with the reference's own
  * fp32 scalar formulas (eq/sdes.py:456-555, 609-678; losses/oc.py:1369-1371).  Column meaning:

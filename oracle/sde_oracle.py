@@ -837,6 +837,29 @@ def langevin_drift(t, x, target_score, prior_score, g, T, clip_score):
     return clip(d, clip_score)
 
 
+def eubo_cmcd(ts, x, ctrl, target_score, prior_score, g, T, clip_score, terminal_logp, initial_logp, noise=None):
+    """losses/oc.py:757-828 ControlledLangevinSDELoss.compute_eubo (use_rescaling=True).  Note :806: the drift at y is
+    evaluated at time t, not s."""
+    noise = noise or TorchNoise()
+    g, T = _t(g), _t(T)
+    rnd = -terminal_logp(x)
+    times_s, times_t = ts[:-1].flip((0,)), ts[1:].flip((0,))
+    for i, (s, t) in enumerate(zip(times_s, times_t)):
+        u_t = ctrl(t, x)
+        dt = t - s
+        db = dt.sqrt() * noise(i, x)
+        drift_t = langevin_drift(t, x, target_score, prior_score, g, T, clip_score)
+        y = x + (drift_t - u_t * g) * dt + g * db
+        drift_s = langevin_drift(t, y, target_score, prior_score, g, T, clip_score)
+        u_s = ctrl(s, y)
+        cost = (drift_s + drift_t) / g + u_s - u_t
+        rnd = rnd - 0.5 * (cost ** 2).sum(dim=-1, keepdim=True) * dt
+        rnd = rnd - (cost * db).sum(dim=-1, keepdim=True)
+        x = y
+    rnd = rnd + initial_logp(x)
+    return x, rnd
+
+
 def simulate_cmcd(ts, x, ctrl, target_score, prior_score, g, T, clip_score, terminal_logp, initial_logp,
                   noise=None, return_traj=False):
     """losses/oc.py:666-755 ControlledLangevinSDELoss.simulate (eval path, use_rescaling=True)."""

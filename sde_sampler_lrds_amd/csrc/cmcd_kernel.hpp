@@ -23,9 +23,12 @@ __host__ __device__ inline int cmcd_lds_floats(int NT, int n_rows) { return sd_l
 // (u, b) at (time index ki, state x): u = ctrl(t, x) (reparam.py:112-117), b = annealed drift (eq/sdes.py:101-110)
 enum { CT_LOGREG = 0, CT_GMM = 1, CT_PHI4 = 2 };  // target kind is a template parameter: one score body per kernel
 
-template <int NT, int TGT>
+// TWO = true also returns b2, the drift with a second pair of annealing weights (the noising loop of compute_eubo
+// needs drift(t, y) for the cost and drift(s, y) for the next move: same scores, two mixes)
+template <int NT, int TGT, bool TWO = false>
 SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float w_t, float w_1mt, const float* lds,
-                         const float* bias, int lane, f32x4 (&u)[NT], f32x4 (&b)[NT]) {
+                         const float* bias, int lane, f32x4 (&u)[NT], f32x4 (&b)[NT], f32x4 (&b2)[NT], float w2_t = 0.0f,
+                         float w2_1mt = 0.0f) {
   constexpr int KB = (NT + 1) / 2;
   const int g = lane >> 4;
   const SimArgs& s = a.s;
@@ -61,14 +64,20 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
       dense_pre<KB, 1>(dh, dl, ps, pm, reinterpret_cast<const f16x8*>(a.prec_pack) + static_cast<size_t>(t) * KB * 2 * 64, lane);
       fold_lo<1>(ps, pm);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) b[t][r] = ts[t][r] * w_t + (-ps[0][r]) * w_1mt;
+      for (int r = 0; r < 4; ++r) {
+        b[t][r] = ts[t][r] * w_t + (-ps[0][r]) * w_1mt;
+        if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + (-ps[0][r]) * w2_1mt;
+      }
     }
   } else if (s.prior.kind == SDENG_DIST_GAUSS_DIAG) {  // Gauss.score (score_gauss, distr/gauss.py:124-126)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const f32x4 pv = gauss_score_tile<NT>(x, s.prior.tab, g, t);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) b[t][r] = ts[t][r] * w_t + pv[r] * w_1mt;
+      for (int r = 0; r < 4; ++r) {
+        b[t][r] = ts[t][r] * w_t + pv[r] * w_1mt;
+        if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + pv[r] * w2_1mt;
+      }
     }
   } else {  // IsotropicGauss.score  distr/gauss.py:764-766
 #pragma unroll
@@ -77,6 +86,7 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
       for (int r = 0; r < 4; ++r) {
         const float pv = feat_lt(t, r, 4 * g, s.d) ? (a.iso_loc - x[t][r]) * a.inv_iso_var : 0.0f;
         b[t][r] = ts[t][r] * w_t + pv * w_1mt;
+        if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + pv * w2_1mt;
       }
   }
 #pragma unroll
@@ -86,6 +96,11 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
       float v = b[t][r] * hg2;
       if (s.cmcd_clip > 0.0f) v = clampf(v, s.cmcd_clip);
       b[t][r] = v;
+      if constexpr (TWO) {
+        float v2 = b2[t][r] * hg2;
+        if (s.cmcd_clip > 0.0f) v2 = clampf(v2, s.cmcd_clip);
+        b2[t][r] = v2;
+      }
     }
 
   // ---- control ----
@@ -113,7 +128,7 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   }
 }
 
-template <int NT, int TGT>
+template <int NT, int TGT, bool EUBO>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(const CmcdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SimArgs& s = a.s;
@@ -143,21 +158,24 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     if (s.xs_out) store_rows<NT>(s.xs_out, trash, row, s.d, live, g, x);
     // carried between steps: w_s = b_s/g + u_s, the only combination of (u_s, b_s) the step needs:
     //   y = x + (b_s + u_s g) dt + g db = x + g w_s dt + g db ;   cost = (b_s + b_t)/g + u_s - u_t = w_s + (b_t/g - u_t)
-    // (16 registers per 64 features less than carrying u_s and b_s; identical arithmetic for g = 1, the conf default)
+    // (16 registers per 64 features less than carrying u_s and b_s; identical arithmetic for g = 1, the conf default).
+    // Noising direction (compute_eubo, losses/oc.py:782-823), rows in iteration order: the move uses -u, so the carried
+    // combination is v = drift(t,x)/g - u(t,x);  cost = v + (drift(t,y)/g + u(s,y));  next v = drift(s,y)/g - u(s,y).
+    constexpr float sgn = EUBO ? -1.0f : 1.0f;
     f32x4 w_s[NT];
     if (s.N > 0) {
       f32x4 u0[NT], b0[NT];
-      cmcd_eval<NT, TGT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, lane, u0, b0);
+      cmcd_eval<NT, TGT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, lane, u0, b0, b0);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w_s[t][r] = b0[t][r] * inv_g + u0[t][r];
+        for (int r = 0; r < 4; ++r) w_s[t][r] = b0[t][r] * inv_g + sgn * u0[t][r];
     }
 
     for (int k = 0; k < s.N; ++k) {
       const float* cf = s.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float dt = cf[2], sqdt = cf[3];
-      // y = x + (b_s + u_s g) dt + g db ,  db = sqrt(dt) z      (losses/oc.py:722-724)
+      // y = x + (b_s + u_s g) dt + g db ,  db = sqrt(dt) z      (losses/oc.py:722-724; :800-802 with -u for the noising loop)
       f32x4 db[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -176,26 +194,32 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
           x[t][r] = x[t][r] + (w_s[t][r] * gg) * dt + gg * dbv;
         }
       }
-      // cost = (b_s + b_t)/g + u_s - u_t ;  rnd += 0.5 |cost|^2 dt + <cost, db>   (losses/oc.py:737-742)
+      // cost = (b_s + b_t)/g + u_s - u_t ;  rnd += 0.5 |cost|^2 dt + <cost, db>   (losses/oc.py:737-742; subtracted at :815-818)
       float c2 = 0.0f, cdb = 0.0f;
       {
-        f32x4 u_t[NT], b_t[NT];
-        cmcd_eval<NT, TGT>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t);
+        f32x4 u_t[NT], b_t[NT], b_n[EUBO ? NT : 1];
+        if constexpr (EUBO) {  // weights of t (cols 6,7 of the row) for the cost, of s (cols 4,5 of the NEXT row) for the next move
+          const float* cn = cf + SDENG_NCOEF;
+          cmcd_eval<NT, TGT, true>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t, b_n, cn[4], cn[5]);
+        } else {
+          cmcd_eval<NT, TGT>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t, b_t);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float bg = b_t[t][r] * inv_g;
-            const float c = w_s[t][r] + (bg - u_t[t][r]);
+            const float c = w_s[t][r] + (bg - sgn * u_t[t][r]);
             c2 = __builtin_fmaf(c, c, c2);
             cdb = __builtin_fmaf(c, db[t][r], cdb);
-            w_s[t][r] = bg + u_t[t][r];
+            if constexpr (EUBO) w_s[t][r] = b_n[t][r] * inv_g - u_t[t][r];
+            else w_s[t][r] = bg + u_t[t][r];
           }
       }
       c2 = group_sum(c2);
       cdb = group_sum(cdb);
-      rnd += (0.5f * c2) * dt;
-      rnd += cdb;
+      rnd += sgn * ((0.5f * c2) * dt);
+      rnd += sgn * cdb;
       if (s.xs_out) store_rows<NT>(s.xs_out + static_cast<size_t>(k + 1) * s.B * s.d, trash, row, s.d, live, g, x);
     }
     store_rows<NT>(s.x_out, trash, row, s.d, live, g, x);
@@ -203,19 +227,23 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
   }
 }
 
-template <int NT, int TGT>
+template <int NT, int TGT, bool EUBO>
 static int launch_cmcd_t(const CmcdArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(cmcd_lds_floats(NT, a.s.lr.n_rows)) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT, TGT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT, TGT, EUBO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_simulate_cmcd<NT, TGT>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_simulate_cmcd<NT, TGT, EUBO>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
 }
 template <int NT>
 static int launch_cmcd(const CmcdArgs& a, int grid, hipStream_t stream) {
-  if (a.s.target.kind == SDENG_DIST_PHI4) return launch_cmcd_t<NT, CT_PHI4>(a, grid, stream);
-  if (a.s.target.kind != SDENG_DIST_LOGREG) return launch_cmcd_t<NT, CT_GMM>(a, grid, stream);
-  if constexpr (NT <= 4) return launch_cmcd_t<NT, CT_LOGREG>(a, grid, stream);
+  if (a.s.form == SDENG_FORM_CMCD_EUBO) {  // noising loop: mixture / Gaussian targets (the targets that can be sampled from)
+    if (a.s.target.kind == SDENG_DIST_GMM_DIAG || a.s.target.kind == SDENG_DIST_GAUSS_DIAG) return launch_cmcd_t<NT, CT_GMM, true>(a, grid, stream);
+    return static_cast<int>(hipErrorInvalidValue);
+  }
+  if (a.s.target.kind == SDENG_DIST_PHI4) return launch_cmcd_t<NT, CT_PHI4, false>(a, grid, stream);
+  if (a.s.target.kind != SDENG_DIST_LOGREG) return launch_cmcd_t<NT, CT_GMM, false>(a, grid, stream);
+  if constexpr (NT <= 4) return launch_cmcd_t<NT, CT_LOGREG, false>(a, grid, stream);
   return static_cast<int>(hipErrorInvalidValue);
 }

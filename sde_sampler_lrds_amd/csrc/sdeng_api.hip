@@ -115,10 +115,10 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.cmcd = o;
   {  // logistic-regression images (CMCD, or the in-loop score of a Score/LerpCtrl) and the CMCD prior's packed precision
     const bool lr_used = d->target.kind == SDENG_DIST_LOGREG && d->target.k > 0 &&
-                         (d->form == SDENG_FORM_CMCD || d->net.ctrl_kind != SDENG_CTRL_CLIPPED);
+                         (d->form == SDENG_FORM_CMCD || d->form == SDENG_FORM_CMCD_EUBO || d->net.ctrl_kind != SDENG_CTRL_CLIPPED);
     const int n = lr_used ? d->target.k : 0;
     o += align64(sd_lr_floats(DT, n)) + align64(32 * sd_lr_row_kb(n));
-    if (d->form == SDENG_FORM_CMCD) o += align64(DT * sd_kb(DT) * 512) + align64(16 * DT);
+    if (d->form == SDENG_FORM_CMCD || d->form == SDENG_FORM_CMCD_EUBO) o += align64(DT * sd_kb(DT) * 512) + align64(16 * DT);
   }
   L.total = o;
   return true;
@@ -307,9 +307,20 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   } else if (d->prior.kind == SDENG_DIST_ISO_GAUSS) {
     c.iso_loc = d->prior.p0; c.inv_iso_var = 1.0f / d->prior.p3;
   }
-  DistEvalArgs e;
-  e.ds = prior; e.B = d->B; e.d = d->d; e.dpad = dpad; e.x = d->x_in; e.logp_out = ws + L.rnd_init; e.score_out = nullptr;
-  SD_HIP(sd_launch_dist_eval(e, s));
+  const bool eubo = d->form == SDENG_FORM_CMCD_EUBO;
+  TerminalArgs t;
+  t.B = d->B; t.d = d->d; t.dpad = dpad;
+  if (eubo) {  // rnd0 = -log pi~(x_in)   (losses/oc.py:779)
+    if (d->target.kind != SDENG_DIST_GMM_DIAG && d->target.kind != SDENG_DIST_GAUSS_DIAG)
+      return fail(SDENG_E_UNSUPPORTED, "CMCD compute_eubo kernels: diagonal Gaussian / mixture targets (kind %d)", d->target.kind);
+    SD_HIP(hipMemsetAsync(ws + L.rnd_init, 0, sizeof(float) * d->B, s));
+    t.ref = target; t.target = target; t.use_ref = 0; t.use_target = 1; t.x = d->x_in; t.rnd = ws + L.rnd_init;
+    SD_HIP(sd_launch_terminal(t, s));
+  } else {     // rnd0 = log p_prior(x0)
+    DistEvalArgs e;
+    e.ds = prior; e.B = d->B; e.d = d->d; e.dpad = dpad; e.x = d->x_in; e.logp_out = ws + L.rnd_init; e.score_out = nullptr;
+    SD_HIP(sd_launch_dist_eval(e, s));
+  }
   a.rnd_init = ws + L.rnd_init;
   a.cmcd_g = d->cmcd_g; a.cmcd_clip = d->cmcd_clip;
   a.target = target; a.prior = prior;
@@ -317,9 +328,10 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
   SD_HIP((DT == 1 ? sd_launch_cmcd_1 : (DT == 2 ? sd_launch_cmcd_2 : (DT == 4 ? sd_launch_cmcd_4 : sd_launch_cmcd_8)))(c, grid_for(a.ntiles), s));
   if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
-  TerminalArgs t;
-  t.ref = target; t.target = target; t.use_ref = 0; t.use_target = 1;
-  t.B = d->B; t.d = d->d; t.dpad = dpad; t.x = d->x_out; t.rnd = d->rnd_out;
+  // terminal: -log pi~(x_N)  (:752), or for the noising loop + log p_prior(x_noised)  (:825)
+  if (eubo) { t.ref = prior; t.target = prior; t.use_ref = 1; t.use_target = 0; }
+  else { t.ref = target; t.target = target; t.use_ref = 0; t.use_target = 1; }
+  t.x = d->x_out; t.rnd = d->rnd_out;
   SD_HIP(sd_launch_terminal(t, s));
   return 0;
 }
@@ -335,7 +347,8 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   if (!d->workspace || d->workspace_bytes < L.total * sizeof(float))
     return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, L.total * sizeof(float));
   if (static_cast<long long>(d->B) * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "B*d >= 2^31");
-  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM && d->form != SDENG_FORM_CMCD && d->form != SDENG_FORM_EUBO)
+  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM && d->form != SDENG_FORM_CMCD && d->form != SDENG_FORM_EUBO &&
+      d->form != SDENG_FORM_CMCD_EUBO)
     return fail(SDENG_E_INVALID, "unknown form %d", d->form);
   const int DT = tiles_of(d->d), dpad = 16 * DT;
   float* ws = static_cast<float*>(d->workspace);
@@ -352,7 +365,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   a.trash = ws + L.trash;
   a.ntiles = (d->B + 15) / 16;
 
-  if (d->form == SDENG_FORM_CMCD) return simulate_cmcd(d, L, ws, DT, a, s);
+  if (d->form == SDENG_FORM_CMCD || d->form == SDENG_FORM_CMCD_EUBO) return simulate_cmcd(d, L, ws, DT, a, s);
   int rc = prepare_net(d, L, ws, DT, a, s, d->N, false, 0.0f);
   if (rc) return rc;
   int sc;

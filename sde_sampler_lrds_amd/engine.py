@@ -281,6 +281,18 @@ def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, alpha=None, si
     'time_reversal' | 'dds' | 'eubo_ei' | 'eubo_em'.  ``ts`` is a CPU tensor; every entry is produced by the reference's scalar formula."""
     ts = ts.detach().to("cpu", torch.float32)
     N = ts.numel() - 1
+    if kind == "cmcd_eubo":  # N+1 rows in iteration order: row k is the evaluation at time ts[N-k] (losses/oc.py:782-823)
+        out = torch.zeros(N + 1, L.NCOEF, dtype=torch.float32)
+        Tstar = sde.terminal_t
+        for k in range(N + 1):
+            tk = ts[N - k]
+            out[k, 0] = tk
+            out[k, 4], out[k, 5] = tk / Tstar, 1.0 - tk / Tstar  # eq/sdes.py:103 at this evaluation's time
+            out[k, 6], out[k, 7] = out[k, 4], out[k, 5]
+            if k < N:
+                dt = ts[N - k] - ts[N - 1 - k]
+                out[k, 2], out[k, 3] = dt, dt.sqrt()
+        return out
     if kind == "cmcd":  # N+1 rows: row k holds the times/weights of step k; the last row only ts[N] (net time)
         out = torch.zeros(N + 1, L.NCOEF, dtype=torch.float32)
         Tstar = sde.terminal_t

@@ -7,9 +7,9 @@ update and log-RND accumulation run inside a single persistent gfx950 kernel.
 
 What is on the HIP path: the eval / sampling direction (``change_sde_ctrl=False``), i.e. what
 ``Trainable.evaluate`` times as ``eval/sample_time`` (solver/oc.py:148-158).  ``compute_eubo`` (the noising loops of
-SURVEY.md 8f-2) is a HIP launch too for the RDS losses and DiscreteTimeReversalLossEI.  The training direction (``__call__``,
+SURVEY.md 8f-2) is a HIP launch too (RDS losses, DiscreteTimeReversalLossEI, CMCD on mixture targets).  The training direction (``__call__``,
 8f-1) is built for the log-variance methods (``_lv_loss``: HIP step loop + one batched autograd pass of the control); KL
-training and the CMCD ``compute_eubo`` raise instead of silently running a PyTorch loop.
+training raises instead of silently running a PyTorch loop.
 
 Extra, engine-only knobs (keyword-only, default to the reference behaviour):
   * ``noise=[N,B,d]`` injects the normals (replays the reference's ``randn_like`` stream, parity mode);
@@ -346,7 +346,7 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
         self.use_rescaling = use_rescaling
 
     def simulate(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, train=True, change_sde_ctrl=False,
-                 return_traj=False, use_ema=False, *, noise=None):
+                 return_traj=False, use_ema=False, *, noise=None, eubo=False):
         self._no_train(change_sde_ctrl)
         if train and self.method in ["kl", "kl_ito"]:
             raise E.UnsupportedByEngine("CMCD KL-training start (rnd0 = 0) is part of the training direction")
@@ -357,7 +357,7 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
         device = x.device
         keep = []
         desc = L.Desc()
-        desc.form = L.FORM_CMCD
+        desc.form = L.FORM_CMCD_EUBO if eubo else L.FORM_CMCD
         desc.flags = L.FLAG_ITO | L.FLAG_INIT_LOGP | L.FLAG_TERM_TARGET
         desc.N = ts.numel() - 1
         desc.seed, desc.particle0 = int(self.seed), int(self.particle0)
@@ -376,11 +376,19 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
         desc.prior = E.dist_desc(prior, device, keep)
         desc.cmcd_g = float(self.sde.diff_coeff)
         desc.cmcd_clip = float(self.sde.clip_score) if self.sde.clip_score else 0.0
-        coef = self._coef(ts, device)
+        coef = self._coef(ts, device, kind="cmcd_eubo") if eubo else self._coef(ts, device)
         keep.append(coef)
         desc.coef = coef.data_ptr()
         x_out, rnd, xs = E.run(desc, x, keep, return_traj=return_traj, noise=noise, events=self.timing_events)
         return x_out, rnd, xs
+
+    def compute_eubo(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, use_ema=False, *, noise=None):
+        """losses/oc.py:757-828: the CMCD loop run from target samples with the control subtracted, one HIP launch
+        (SDENG_FORM_CMCD_EUBO; diagonal Gaussian / mixture targets -- the ones that can be sampled).  ``x`` is NOT modified
+        (upstream rebinds it, :820)."""
+        _, rnd, _ = self.simulate(ts, x, terminal_unnorm_log_prob, initial_log_prob=initial_log_prob, train=False, use_ema=use_ema,
+                                  noise=noise, eubo=True)
+        return rnd
 
 
     def __call__(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None):

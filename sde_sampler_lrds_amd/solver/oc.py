@@ -245,6 +245,7 @@ class CMCD(_InitialLogProbSolver):
         if not isinstance(self.prior, (Gauss, GaussFull)):
             raise ValueError("Can only be used with gaussian prior.")
         self.loss = self.make_loss()
+        self.eubo_available = hasattr(self.target, "loc") and hasattr(self.target, "sample")  # mixture targets: HIP noising loop
 
     def update_prior(self, mean, var):
         dim = mean.shape[0]

@@ -41,6 +41,8 @@ def build(c, device):
         kind = "rds_gmm"
     if kind == "eubo_dis":
         kind = "dis_ei"
+    if kind == "eubo_cmcd":
+        kind = "cmcd_gmm"
     if kind in ("rds_gmm", "rds_default"):
         sde = make_sde(m)
         target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())

@@ -535,6 +535,26 @@ def case_cmcd_logreg(name, B, N, seed, dt):
     finish(name, meta, arrays, res, draws)
 
 
+def case_eubo_cmcd(name, d, K, B, N, seed):
+    """ControlledLangevinSDELoss.compute_eubo (losses/oc.py:757-828) on a mixture target, IsotropicGauss prior."""
+    torch.manual_seed(seed)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=2.0)
+    sde = r_sdes.ControlledLangevinSDE(target_score=target.score, prior_score=prior.score, diff_coeff=1.0, terminal_t=1.0, clip_score=1e5)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.01), target_score=target.score,
+                           detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
+    loss = r_oc.ControlledLangevinSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    ts = torch.linspace(0.0, 1.0, N + 1)
+    comp = torch.arange(B) % K
+    x0 = target.loc[comp] + math.sqrt(0.5) * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    rnd, draws = run_with_replay(seed, lambda: loss.compute_eubo(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
+    meta = dict(kind="eubo_cmcd", d=d, K=K, B=B, N=N, seed=seed, diff_coeff=1.0, T=1.0, clip_langevin=1e5, clip_model=1e4, clip_score=1e4,
+                scale_score=1.0, prior_kind="iso", prior_scale=2.0, draws=draws)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights,
+                  **pack_params("ctrl.", sd(ctrl)))
+    save(name, meta, arrays)
+
+
 def case_cmcd_phi4(name, d, B, N, seed):
     """CMCD on the phi^4 lattice (conf/solver/cmcd.yaml with conf/target/phi_four.yaml), IsotropicGauss prior."""
     torch.manual_seed(seed)
@@ -763,6 +783,7 @@ CASES = {
     "eubo_ei_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=62, integrator="ei"),
     "eubo_em_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=63, integrator="em"),
     "eubo_dis_ei_d8": lambda n: case_eubo_dis(n, d=8, K=4, B=64, N=32, seed=64),
+    "eubo_cmcd_gmm_d16": lambda n: case_eubo_cmcd(n, d=16, K=4, B=64, N=32, seed=65),
     # log-variance training evaluation (loss + gradients) of the RDS losses
     "train_lv_ei_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=71, integrator="ei"),
     "train_lv_em_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=72, integrator="em"),

@@ -22,7 +22,7 @@ SIM_CASES = [
 ]
 
 
-EUBO_CASES = ["eubo_ei_gmm_d128_k4", "eubo_ei_gmm_d16_k4", "eubo_em_gmm_d16_k4", "eubo_dis_ei_d8"]  # compute_eubo (noising direction)
+EUBO_CASES = ["eubo_ei_gmm_d128_k4", "eubo_ei_gmm_d16_k4", "eubo_em_gmm_d16_k4", "eubo_dis_ei_d8", "eubo_cmcd_gmm_d16"]  # compute_eubo (noising direction)
 
 
 class Case:
@@ -52,8 +52,15 @@ def make_sde(m):
 def run_oracle_eubo(c: Case, noise=None):
     """Oracle restatement of ``compute_eubo`` for an EUBO case -> (noised x, rnd)."""
     m = c.meta
-    sde = make_sde(m)
     tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+    if m["kind"] == "eubo_cmcd":
+        prior = orc.IsoGauss(m["d"], 0.0, m["prior_scale"])
+        ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score, clip_score=m["clip_score"],
+                        scale_score=m["scale_score"])
+        with torch.no_grad():
+            return orc.eubo_cmcd(c["ts"], c["x0"], ctrl, tgt.score, prior.score, m["diff_coeff"], m["T"], m["clip_langevin"], tgt.logp,
+                                 prior.logp, noise or orc.PhiloxNoise(m["seed"]))
+    sde = make_sde(m)
     if m["kind"] == "eubo_dis":
         prior = orc.IsoGauss(m["d"], 0.0, 1.0)
         ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score, clip_score=m["clip_score"],

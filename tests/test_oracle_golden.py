@@ -32,7 +32,8 @@ def test_compute_eubo_matches_reference(name):
     """losses/oc.py:298-362 / :512-568 restated (oracle.eubo_em_ref / eubo_ei_ref) vs the reference's own output."""
     c = gc.load(name)
     x, rnd = gc.run_oracle_eubo(c)
-    assert gc.rel_err(x, c["out_x"]) < TOL_SIM
+    if "out_x" in c.a:  # (the CMCD fixture stores the log-ratio only: upstream rebinds x instead of noising it in place)
+        assert gc.rel_err(x, c["out_x"]) < TOL_SIM
     assert float((rnd - c["rnd"]).abs().max()) < TOL_SIM * max(1.0, float(c["rnd"].abs().max()))
 
 
