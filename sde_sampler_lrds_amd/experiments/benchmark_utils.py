@@ -150,3 +150,32 @@ def fit_gmm(n_components, dataset, means_init=None, em_type="diag", max_iter=100
             last = e
     raise ValueError(f"Couldn't fit a GMM on this dataset. ({last})")
 
+
+def mcmc_sample(device, target, x_init, mcmc_type="mala", step_size=1e-3, n_chains_per_mode=4, dataset_length=50000,
+                n_warmup_steps=512, skip_chain_per_mode=False, target_log_prob_and_grad=None, adapt_step_size=True, shuffle=True,
+                verbose=False):
+    """experiments/benchmark_utils.py:268-333: chains started at ``x_init`` (one group per mode) producing the data set the
+    reference mixture is fitted to.  The target's log-density and score come from the HIP distribution kernels."""
+    from ..additions import mcmc
+    target = target.to(device)
+    if target_log_prob_and_grad is None:
+        target_log_prob_and_grad = mcmc.hip_log_prob_and_grad(target)
+    x_init = x_init.to(device)
+    y = x_init.clone() if skip_chain_per_mode else x_init.repeat_interleave(n_chains_per_mode, dim=0)
+    n_chains = y.shape[0]
+    n_mcmc_steps = int(dataset_length / n_chains)
+    step = step_size * torch.ones((n_chains, 1), device=device)
+    lp, grad = target_log_prob_and_grad(y)
+    ys = torch.empty((n_mcmc_steps, *y.shape))
+    for step_id in range(n_warmup_steps + n_mcmc_steps):
+        if mcmc_type == "mala":
+            y, lp, grad, log_acc = mcmc.mala_step(y, lp, grad, target_log_prob_and_grad, step)
+        else:
+            y, lp, log_acc = mcmc.rwmh_step(y, lp, lambda v: target_log_prob_and_grad(v)[0], step)
+        if adapt_step_size:
+            step = mcmc.heuristics_step_size(step, log_acc)
+        if step_id >= n_warmup_steps:
+            ys[step_id - n_warmup_steps] = y.detach().cpu()
+    ret = ys.view((-1, *x_init.shape[1:]))
+    return ret[torch.randperm(ret.shape[0])] if shuffle else ret
+

@@ -66,3 +66,23 @@ def test_trainable_wrapper_evaluate_with_eubo_metrics(gpu):
     assert 0.0 < res.metrics["eval/norm_effective_sample_size_f"] <= 1.0 + 1e-6
     # ELBO <= log Z <= EUBO  (log Z = 0 for the normalised mixture target); sampling noise leaves slack
     assert res.metrics["eval/elbo"] <= res.metrics["eval/eubo"] + 1e-3
+
+
+@pytest.mark.gpu
+def test_learned_reference_pipeline(gpu):
+    """The LRDS recipe end to end on the engine: MALA chains on the target (HIP log-density / score) -> fit_gmm -> RDS with
+    the fitted mixture as reference -> a few log-variance training steps -> evaluation with EUBO metrics."""
+    from sde_sampler_lrds_amd.additions.hacking import TrainableWrapper
+    from sde_sampler_lrds_amd.experiments.benchmark_utils import _make_target, fit_gmm, mcmc_sample
+    details = make_target_details("many_modes", dim=8, n_modes=4)
+    target = _make_target(details)
+    data = mcmc_sample(gpu, target, target.loc.clone(), step_size=5e-2, n_chains_per_mode=32, dataset_length=8192, n_warmup_steps=64)
+    assert data.shape == (8192, 8) and torch.isfinite(data).all()
+    weights, means, variances = fit_gmm(4, data, means_init=target.loc.cpu())
+    assert float((means - target.loc.cpu()).abs().max()) < 0.5  # the chains stayed on their modes
+    model = make_model("vp-ref", "gmm", "lv", "ei", "base_zero_init", "uniform",
+                       dict(means_ref=means, variances_ref=variances, weights_ref=weights), details,
+                       dict(train_steps=30, train_batch_size=256, eval_batch_size=2048), optim_details=dict(lr=1e-3), n_steps=32)
+    res = TrainableWrapper(model, verbose=False).run()
+    assert math.isfinite(res.metrics["eval/elbo"]) and math.isfinite(res.metrics["eval/eubo"])
+    assert res.metrics["eval/norm_effective_sample_size"] > 0.2  # a good reference makes the sampler nearly exact already
