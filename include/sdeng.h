@@ -225,6 +225,9 @@ size_t sdeng_dist_workspace_bytes(const sdeng_dist* dist, int32_t d);
 /* Counter-based normals exactly as the step loop draws them: out[B,d] for one step. */
 int sdeng_philox_normal(uint64_t seed, int32_t step, int64_t particle0, int32_t B, int32_t d, uint32_t stream_id,
                         float* out, void* stream);
+/* The same for n_steps consecutive steps in one launch: out[n_steps,B,d] (the noise a training call keeps, losses/oc.py:277, :537). */
+int sdeng_philox_normal_steps(uint64_t seed, int32_t step0, int32_t n_steps, int64_t particle0, int32_t B, int32_t d,
+                              uint32_t stream_id, float* out, void* stream);
 
 #ifdef __cplusplus
 }

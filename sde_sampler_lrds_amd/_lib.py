@@ -64,7 +64,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsdeng.so
 
 EXPORTS = ["sdeng_abi_version", "sdeng_last_error", "sdeng_workspace_bytes", "sdeng_simulate", "sdeng_logz",
            "sdeng_logz_workspace_bytes", "sdeng_ctrl_forward", "sdeng_dist_eval", "sdeng_dist_workspace_bytes",
-           "sdeng_philox_normal"]
+           "sdeng_philox_normal", "sdeng_philox_normal_steps"]
 
 
 def lib() -> C.CDLL:
@@ -93,6 +93,8 @@ def lib() -> C.CDLL:
     L.sdeng_dist_workspace_bytes.argtypes = [C.POINTER(Dist), C.c_int32]
     L.sdeng_philox_normal.restype = C.c_int
     L.sdeng_philox_normal.argtypes = [C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.sdeng_philox_normal_steps.restype = C.c_int
+    L.sdeng_philox_normal_steps.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
     if L.sdeng_abi_version() != ABI_VERSION:
         raise ImportError(f"libsdeng.so ABI {L.sdeng_abi_version()} != binding ABI {ABI_VERSION}")
     _LIB = L

@@ -512,16 +512,18 @@ __global__ void k_softmax_weights(const float* rnd, long long B, const float* st
   w[i] = expf((-rnd[i]) - stats[4]) / stats[5];
 }
 
+// grid.y = number of consecutive steps: block row y writes out[y][B][d] for step `step + y`
 __global__ void k_philox(unsigned seed_lo, unsigned seed_hi, int step, long long particle0, int B, int d, unsigned stream_id,
                          float* out) {
   const int nj = (d + 3) / 4;
   const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
   if (idx >= static_cast<long long>(B) * nj) return;
   const int row = static_cast<int>(idx / nj), jb = static_cast<int>(idx % nj);
-  const f32x4 z = philox_normal4(static_cast<uint32_t>(particle0 + row), static_cast<uint32_t>(step), static_cast<uint32_t>(jb),
+  const f32x4 z = philox_normal4(static_cast<uint32_t>(particle0 + row), static_cast<uint32_t>(step) + blockIdx.y, static_cast<uint32_t>(jb),
                                  stream_id, seed_lo, seed_hi);
+  float* o = out + static_cast<size_t>(blockIdx.y) * B * d;
   for (int e = 0; e < 4; ++e)
-    if (4 * jb + e < d) out[static_cast<size_t>(row) * d + 4 * jb + e] = z[e];
+    if (4 * jb + e < d) o[static_cast<size_t>(row) * d + 4 * jb + e] = z[e];
 }
 
 // ---- host-side launch wrappers -------------------------------------------------------------------
@@ -562,8 +564,12 @@ int sd_launch_logz(const float* rnd, long long B, float* stats, float* weights, 
   if (weights) hipLaunchKernelGGL(k_softmax_weights, dim3(static_cast<unsigned>((B + 255) / 256)), dim3(256), 0, s, rnd, B, stats, weights);
   return static_cast<int>(hipGetLastError());
 }
-int sd_launch_philox(unsigned lo, unsigned hi, int step, long long p0, int B, int d, unsigned stream_id, float* out, hipStream_t s) {
+int sd_launch_philox(unsigned lo, unsigned hi, int step, int n_steps, long long p0, int B, int d, unsigned stream_id, float* out, hipStream_t s) {
   const long long n = static_cast<long long>(B) * ((d + 3) / 4);
-  hipLaunchKernelGGL(k_philox, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, lo, hi, step, p0, B, d, stream_id, out);
+  for (int done = 0; done < n_steps; done += 65535) {  // grid.y limit
+    const int chunk = n_steps - done < 65535 ? n_steps - done : 65535;
+    hipLaunchKernelGGL(k_philox, dim3(static_cast<unsigned>((n + 255) / 256), chunk), dim3(256), 0, s, lo, hi, step + done, p0, B, d, stream_id,
+                       out + static_cast<size_t>(done) * B * d);
+  }
   return static_cast<int>(hipGetLastError());
 }

@@ -536,9 +536,13 @@ extern "C" int sdeng_logz(const float* rnd, int64_t B, float* stats, float* weig
 
 extern "C" int sdeng_philox_normal(uint64_t seed, int32_t step, int64_t particle0, int32_t B, int32_t d, uint32_t stream_id, float* out,
                                    void* stream) {
-  if (!out || B < 0 || d < 1) return fail(SDENG_E_INVALID, "bad argument");
-  if (B == 0) return 0;
-  SD_HIP(sd_launch_philox(static_cast<unsigned>(seed & 0xFFFFFFFFull), static_cast<unsigned>(seed >> 32), step, particle0, B, d, stream_id,
-                          out, static_cast<hipStream_t>(stream)));
+  return sdeng_philox_normal_steps(seed, step, 1, particle0, B, d, stream_id, out, stream);
+}
+extern "C" int sdeng_philox_normal_steps(uint64_t seed, int32_t step0, int32_t n_steps, int64_t particle0, int32_t B, int32_t d,
+                                         uint32_t stream_id, float* out, void* stream) {
+  if (!out || B < 0 || d < 1 || n_steps < 0) return fail(SDENG_E_INVALID, "bad argument");
+  if (B == 0 || n_steps == 0) return 0;
+  SD_HIP(sd_launch_philox(static_cast<unsigned>(seed & 0xFFFFFFFFull), static_cast<unsigned>(seed >> 32), step0, n_steps, particle0, B, d,
+                          stream_id, out, static_cast<hipStream_t>(stream)));
   return 0;
 }

@@ -438,8 +438,7 @@ def philox_noise(seed: int, N: int, B: int, d: int, particle0: int, device) -> t
     """[N,B,d] normals of the step loop's counter-based stream (the kernel draws exactly these when no noise is injected)."""
     lib = L.lib()
     out = torch.empty(N, B, d, dtype=torch.float32, device=device)
-    for k in range(N):
-        L.check(lib.sdeng_philox_normal(int(seed), k, int(particle0), B, d, 0, out[k].data_ptr(), _stream_ptr(device)))
+    L.check(lib.sdeng_philox_normal_steps(int(seed), 0, N, int(particle0), B, d, 0, out.data_ptr(), _stream_ptr(device)))
     return out
 
 

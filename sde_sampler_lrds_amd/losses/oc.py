@@ -28,6 +28,33 @@ from .. import engine as E
 from ..utils.common import Results, make_results
 
 
+def ctrl_batched(ctrl, t_unique: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """``ctrl(t, x)`` (with autograd) for M distinct times and B states per time, x [M,B,d] -> [M*B,d].  Same operations
+    as the modules' own forward (models/mlp.py, models/reparam.py), except that the time embeddings -- functions of t only --
+    are evaluated once per distinct time instead of once per row (the reference recomputes them for every particle,
+    models/mlp.py:136-137); other control types fall back to the plain per-row call."""
+    from ..models.reparam import _clip
+    M, B, d = x.shape
+    flat = x.reshape(M * B, d)
+    t_rows = t_unique.repeat_interleave(B).view(-1, 1)
+    name, net = type(ctrl).__name__, getattr(ctrl, "base_model", None)
+    if name not in ("ClippedCtrl", "ScoreCtrl", "LerpCtrl") or type(net).__name__ != "FourierMLP":
+        return ctrl(t_rows, flat)
+    h = net.input_embed(flat) + net.timestep_embed(t_unique.view(-1, 1)).repeat_interleave(B, dim=0)
+    for layer in net.hidden_layer:
+        h = layer(net.activation(h))
+    out = _clip(net.out_layer(net.activation(h)), ctrl.clip_model)
+    if name == "ClippedCtrl":
+        return out
+    if name == "ScoreCtrl":
+        score = ctrl.scale_score * ctrl.clipped_target_score(t_rows, flat)
+    else:
+        score = ctrl.scale_score * ctrl.clipped_interpolated_score(t_rows, flat)
+    if ctrl.score_model is not None:
+        score = score * _clip(ctrl.score_model(t_unique.view(-1, 1)), ctrl.clip_model).repeat_interleave(B, dim=0)
+    return out + (ctrl.sde.diff(t_rows, flat) * score if name == "LerpCtrl" else score)
+
+
 class BaseOCLoss:
     """Mirror of losses/oc.py:14-200."""
 
@@ -137,8 +164,7 @@ class BaseOCLoss:
                 const = const + rnd0(x).view((-1, 1))
         coef = self._coef(ts, x.device, **(coef_kw or {}))
         c_run = (2.0 * coef[:, 4]) if lin else coef[:, 4]  # omega | beta^2 sigma^2 (LIN forms)  or dt (EM)
-        t_rows = coef[:, 0].repeat_interleave(B).view(-1, 1)  # the net's time for every row of step k
-        u = self.generative_ctrl(t_rows, xs[:-1].reshape(N * B, d))
+        u = ctrl_batched(self.generative_ctrl, coef[:, 0], xs[:-1])  # coef[:, 0]: the net's time of step k
         rnd = ((u * (u.detach() - 0.5 * u)).sum(dim=-1).view(N, B) * c_run.view(N, 1)).sum(dim=0)
         if ito:
             rnd = rnd + ((u * z.view(N * B, d)).sum(dim=-1).view(N, B) * coef[:, 5].view(N, 1)).sum(dim=0)
@@ -428,8 +454,7 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
             const = -terminal_unnorm_log_prob(x_n)
             if initial_log_prob is not None:
                 const = const + initial_log_prob(x).view((-1, 1))
-        t_rows = ts.to(x.device).repeat_interleave(B).view(-1, 1)
-        u = self.generative_ctrl(t_rows, flat).view(N + 1, B, d)
+        u = ctrl_batched(self.generative_ctrl, ts.to(x.device), xs).view(N + 1, B, d)
         dt = (ts[1:] - ts[:-1]).view(N, 1, 1)
         db = dt.sqrt() * z
         cost = (b_s + b_t) / g + u[:-1] - u[1:]
