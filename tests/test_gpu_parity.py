@@ -148,6 +148,22 @@ def test_philox_kernel_vs_oracle(gpu):
 
 
 @pytest.mark.gpu
+def test_multi_step_philox_equals_single_steps(gpu):
+    """sdeng_philox_normal_steps (one launch for N steps: the noise a training call keeps) == N calls of sdeng_philox_normal."""
+    from sde_sampler_lrds_amd import _lib as L
+    from sde_sampler_lrds_amd import engine as E
+    N, B, d, seed, p0 = 7, 333, 29, 987654321987, 4096
+    many = E.philox_noise(seed, N, B, d, p0, gpu)
+    one = torch.empty(B, d, device=gpu)
+    for k in range(N):
+        L.check(L.lib().sdeng_philox_normal(seed, k, p0, B, d, 0, one.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(many[k], one)
+    ref = orc.philox_normal(seed, 3, p0, B, d)
+    assert float((many[3].cpu() - ref).abs().max()) < 5e-6
+
+
+@pytest.mark.gpu
 def test_empty_batch_and_bad_descriptor(gpu):
     from sde_sampler_lrds_amd import engine as E
     c = gc.load("rds_ei_gmm_d8_k4")
