@@ -16,7 +16,7 @@
 //
 // Why 16-particle tiles (an earlier build used 32x32x2 MFMA, 32 particles per wave): the state of a tile is
 // half as many registers per lane (d=128: 32 instead of 64), so the whole step loop at d=128 fits the 256-VGPR
-// budget of 2 waves per SIMD with NO scratch traffic (235 VGPRs, 0 spills).  Measured on MI355X, cfg 2:
+// budget of 2 waves per SIMD with NO scratch traffic (208 VGPRs, 0 spills).  Measured on MI355X, cfg 2:
 // 4 waves/SIMD (128 VGPRs, spills) 10.2 ms, 2 waves/SIMD 7.6 ms, 1 wave/SIMD 9.6 ms.  On gfx950 MFMA and
 // VALU issue of the waves of one SIMD do not overlap (tools/ubench/pipe_share.hip), so extra occupancy buys
 // nothing once memory latency is covered; instruction count is what matters.
