@@ -386,6 +386,22 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
       SD_HIP(sd_launch_ref_tables(r, d->N, s));
     }
     a.ref_k = K;
+    if (rf == RF_GMM_BIG) {
+      // workgroup-shared table copy: two LDS buffers of whole 1 KiB chunks behind the drift-net weights (160 KiB of
+      // LDS per workgroup), each holding a piece of kc components -- the whole table when it fits, otherwise the
+      // fewest equal pieces that do.  SDENG_REF_SHARE=0 keeps the streamed-from-L2 path (A/B measurements).
+      static const bool allow = [] { const char* e = getenv("SDENG_REF_SHARE"); return !(e && e[0] == '0'); }();
+      const int room = (160 * 1024 - static_cast<int>(sizeof(float)) * sd_lds_weight_floats(DT)) / 2 / static_cast<int>(sizeof(float));
+      const int cap = std::min(room, sd_share_buf_floats(SD_SHARE_MAX)) / 256 * 256;  // floats per buffer
+      const int kc_max = cap / (2 * dpad);
+      if (allow && kc_max >= 1) {
+        const int nch = (K + kc_max - 1) / kc_max;
+        const int kc = (K + nch - 1) / nch;
+        const int chunks = (kc * 2 * dpad + 255) / 256;
+        a.ref_share = (chunks + SD_WAVES - 1) / SD_WAVES;
+        a.ref_kc = kc;
+      }
+    }
     a.ref_tab = ws + L.ref_tab; a.ref_consts = ws + L.ref_consts;
     a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
   } else if (d->ref.kind != SDENG_REF_NONE) {

@@ -47,6 +47,9 @@ __host__ __device__ inline int sd_off_bias(int NT) { return sd_lds_weight_floats
 __host__ __device__ inline int sd_pack_floats(int NT) { return sd_lds_weight_floats(NT) + 3 * 64 + 16 * NT; }
 // per-wave LDS copy of one step's reference table [K][2][dpad]; used while K*2*dpad <= SD_REFTAB_FLOATS
 #define SD_REFTAB_FLOATS 1024
+// workgroup-shared copy of a larger mixture's table (RF_GMM_BIG): `share` chunks of 1 KiB per wave, two buffers
+#define SD_SHARE_MAX 4
+__host__ __device__ inline int sd_share_buf_floats(int share) { return share * SD_WAVES * 256; }
 __host__ __device__ inline int sd_lds_total_bytes(int NT, bool with_ref) {
   return (sd_lds_weight_floats(NT) + (with_ref ? SD_WAVES * SD_REFTAB_FLOATS : 0)) * 4;
 }
@@ -90,6 +93,8 @@ struct SimArgs {
   int ctrl_kind;
   float clip_model, clip_score, scale_score;
   int ref_k;
+  int ref_share;            // RF_GMM_BIG: > 0 = 1 KiB chunks per wave of the workgroup-shared, double-buffered table copy
+  int ref_kc;               //   components per staged piece of the table (>= ref_k: the whole table in one piece)
   const float* ref_tab;     // [N][K][2][dpad]
   const float* ref_consts;  // [N][K][2]  (0.5*sum log var, log w)
   float ref_c1;             // 0.5*d*log(2*pi)

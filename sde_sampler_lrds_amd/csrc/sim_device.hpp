@@ -269,6 +269,19 @@ SD_INLINE void dma_table_to_lds(const float* __restrict__ gsrc, float* lds_dst, 
   if (n_floats > 768) __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
   static_assert(SD_REFTAB_FLOATS <= 1024, "four 1 KiB chunks");
 }
+// One step's table of a larger mixture, copied once per WORKGROUP: wave w moves chunks [w*share, (w+1)*share).
+SD_INLINE void dma_table_shared(const float* __restrict__ gsrc, float* lds_buf, int n_floats, int share, int wave, int lane) {
+  typedef __attribute__((address_space(1))) void gvoid;
+  typedef __attribute__((address_space(3))) void lvoid;
+  const int f0 = wave * share * 256;  // first float of this wave's slice (wave-uniform)
+  gvoid* g = (gvoid*)(gsrc + f0 + lane * 4);
+  lvoid* l = (lvoid*)(lds_buf + f0);
+  if (f0 < n_floats) __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+  if (share > 1 && f0 + 256 < n_floats) __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+  if (share > 2 && f0 + 512 < n_floats) __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+  if (share > 3 && f0 + 768 < n_floats) __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+  static_assert(SD_SHARE_MAX == 4, "four 1 KiB chunks per wave");
+}
 #ifdef SD_DBG_WAITMORE
 SD_INLINE void wait_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_sleep 8\n\ts_nop 7" ::: "memory"); }
 #else
@@ -353,33 +366,72 @@ SD_INLINE float gmm_logit(const f32x4 (&x)[NT], const float* __restrict__ tab, c
   return consts[k * cstride + 1] + v;
 }
 
-// any K: online softmax over components, score accumulated in a d-wide register array
+// any K: online softmax over components, score accumulated in a d-wide register array.  One pass over the
+// table per component: q = (x - m)/var is kept from the logit's quadratic form (sum (x - m) q) and reused for
+// the score term -p_k q, and the accumulator is rescaled only when some particle of the wave found a new
+// maximum (exp(0) = 1 otherwise, so skipping the multiply is exact).
 template <int NT>
-SD_INLINE void gmm_score(const f32x4 (&x)[NT], const float* __restrict__ tab, const float* __restrict__ consts,
-                         int cstride, int K, float c1, int g, f32x4 (&acc)[NT]) {
+SD_INLINE void gmm_score_accum(const f32x4 (&x)[NT], const float* __restrict__ tab, const float* __restrict__ consts,
+                               int cstride, int K, float c1, int g, f32x4 (&acc)[NT], float& m_run, float& l_run) {
   constexpr int dpad = 16 * NT;
-  float m_run = -INFINITY, l_run = 0.0f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   for (int k = 0; k < K; ++k) {
-    const float lp = gmm_logit<NT>(x, tab, consts, cstride, k, c1, g);
-    const float m_new = fmaxf(m_run, lp);
-    const float so = expf(m_run - m_new);
-    const float pk = expf(lp - m_new);
-    l_run = l_run * so + pk;
-    m_run = m_new;
     const float* mp = tab + static_cast<size_t>(k) * 2 * dpad;
+    f32x4 q[NT];
+    float part = 0.0f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const f32x4 m = load_tile4(mp, t, g);
       const f32x4 iv = load_tile4(mp + dpad, t, g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(pk, (m[r] - x[t][r]) * iv[r], acc[t][r] * so);  // -(x-mean)/var
+      for (int r = 0; r < 4; ++r) {
+        const float dl = x[t][r] - m[r];
+        q[t][r] = dl * iv[r];
+        part = __builtin_fmaf(dl, q[t][r], part);
+      }
     }
+    part = group_sum(part);
+    const float v = ((-0.5f * part) - c1) - consts[k * cstride + 0];
+    const float lp = consts[k * cstride + 1] + v;
+    const float m_new = fmaxf(m_run, lp);
+    const float so = expf(m_run - m_new);
+    const float pk = expf(lp - m_new);
+    l_run = l_run * so + pk;
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(pk, -q[t][r], acc[t][r] * so);  // -(x-mean)/var
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_fmaf(pk, -q[t][r], acc[t][r]);
+    }
+    m_run = m_new;
   }
+}
+// the online-softmax accumulator over a table in one piece (global memory, or one LDS chunk holding all K components);
+// a table staged in several chunks calls begin / accum per chunk / end -- the same operations in the same order
+template <int NT>
+SD_INLINE void gmm_score_begin(f32x4 (&acc)[NT], float& m_run, float& l_run) {
+  m_run = -INFINITY;
+  l_run = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+template <int NT>
+SD_INLINE void gmm_score_end(f32x4 (&acc)[NT], float l_run) {
   const float inv = 1.0f / l_run;
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = acc[t] * inv;
+}
+template <int NT>
+SD_INLINE void gmm_score(const f32x4 (&x)[NT], const float* __restrict__ tab, const float* __restrict__ consts,
+                         int cstride, int K, float c1, int g, f32x4 (&acc)[NT]) {
+  float m_run, l_run;
+  gmm_score_begin<NT>(acc, m_run, l_run);
+  gmm_score_accum<NT>(x, tab, consts, cstride, K, c1, g, acc, m_run, l_run);
+  gmm_score_end<NT>(acc, l_run);
 }
 
 // Small-mixture variant (K <= SD_KREG; the reference's default n_modes is 4, conf/target/many_modes.yaml):

@@ -61,6 +61,13 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 #endif
   float* my_tab = lds + sd_lds_weight_floats(NT) + wave * SD_REFTAB_FLOATS;
   const int tab_floats = a.ref_k * 2 * dpad;
+  // larger mixtures: the workgroup shares one LDS copy of the step's table, double-buffered behind the weights
+  // (one LDS-DMA copy per WORKGROUP instead of every wave streaming the table from L2).  Its 8 waves then
+  // walk rounds and steps in lock-step -- one barrier per table piece, reached by every wave: a wave whose tile index is
+  // past the end computes on zeros with all stores masked, so trip counts are uniform by construction.
+  const int share = REF == RF_GMM_BIG ? __builtin_amdgcn_readfirstlane(a.ref_share) : 0;
+  float* sh_tab = lds + sd_lds_weight_floats(NT);
+  const int sh_floats = sd_share_buf_floats(share);
   const int p = lane & 15, g = lane >> 4;
   constexpr bool lin = FORM == SDENG_FORM_LIN;
   constexpr bool eubo = FORM == SDENG_FORM_EUBO;  // noising direction (compute_eubo)
@@ -68,7 +75,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   const bool full_d = a.d == dpad;
   float* trash = a.trash + tid * 4;
 
-  for (int tile = blockIdx.x + gridDim.x * wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {  // CUs first
+  // CUs first; shared-table mode: the round's wave-0 tile decides, so all 8 waves run the same rounds
+  for (int tile = blockIdx.x + gridDim.x * wave; (share ? tile - static_cast<int>(gridDim.x) * wave : tile) < a.ntiles;
+       tile += gridDim.x * SD_WAVES) {
     const uint32_t row = static_cast<uint32_t>(tile) * 16u + p;
     const bool live = row < static_cast<uint32_t>(a.B);
     const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
@@ -82,6 +91,12 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     }
     if constexpr (ref_lds) {
       if (a.N > 0) dma_table_to_lds(a.ref_tab, my_tab, tab_floats, lane);
+    }
+    if constexpr (REF == RF_GMM_BIG) {
+      if (share) {  // the previous round's last reads of buffer 0 are done once every wave is here
+        __syncthreads();
+        if (a.N > 0) dma_table_shared(a.ref_tab, sh_tab, min(a.ref_kc, a.ref_k) * 2 * dpad, share, wave, lane);
+      }
     }
 
     for (int k = 0; k < a.N; ++k) {  // EUBO: the host lays the rows out in iteration order (times T - s run backwards)
@@ -145,7 +160,32 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 #else
       if constexpr (REF == RF_GMM) gmm_resp<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, resp);
 #endif
-      if constexpr (REF == RF_GMM_BIG) gmm_score<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, rs);
+      if constexpr (REF == RF_GMM_BIG) {
+        if (share) {
+          // The table of step k arrives in nch pieces of <= kc components (one piece when two copies of the whole
+          // table fit); piece q = k*nch + c lives in buffer q & 1.  Per piece: my slice of it (issued one piece ago)
+          // has landed, and after the barrier so has everyone's; every wave is also past its reads of piece q-1,
+          // whose buffer the copy of piece q+1 now overwrites.  The accumulator runs over the components in the
+          // same order as the one-piece form, so chunking does not change a bit of the result.
+          const int kc = a.ref_kc, nch = (a.ref_k + kc - 1) / kc;
+          float m_run, l_run;
+          gmm_score_begin<NT>(rs, m_run, l_run);
+          for (int c = 0; c < nch; ++c) {
+            const int q = k * nch + c;
+            wait_dma();
+            __syncthreads();
+            const int c2 = c + 1 < nch ? c + 1 : 0, k2 = c + 1 < nch ? k : k + 1;
+            if (k2 < a.N)
+              dma_table_shared(a.ref_tab + static_cast<size_t>(k2) * tab_floats + c2 * kc * 2 * dpad,
+                               sh_tab + ((q + 1) & 1) * sh_floats, min(kc, a.ref_k - c2 * kc) * 2 * dpad, share, wave, lane);
+            gmm_score_accum<NT>(x, sh_tab + (q & 1) * sh_floats, rcs + c * kc * 2, 2, min(kc, a.ref_k - c * kc), a.ref_c1, g, rs,
+                                m_run, l_run);
+          }
+          gmm_score_end<NT>(rs, l_run);
+        } else {
+          gmm_score<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, rs);
+        }
+      }
       float st = 1.0f;
       if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[k] : 1.0f;
 
@@ -313,7 +353,8 @@ static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
 template <int NT, int REF, int SC, int FORM, int PAR>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM)) +
-                           (SC == SC_LOGREG ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0);
+                           (SC == SC_LOGREG ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0) +
+                           (REF == RF_GMM_BIG ? sizeof(float) * 2 * sd_share_buf_floats(a.ref_share) : 0);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);

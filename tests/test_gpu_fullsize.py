@@ -118,6 +118,36 @@ def test_cfg4_cmcd_logreg_shard_65536x256(gpu):
     _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(ornd.abs().max()))), "cfg4")
 
 
+# ---- larger mixtures (K > 4): the workgroup-shared, double-buffered table copy -------------------------------------------
+# 1-4 LDS-DMA chunks per wave, idle DMA waves (K = 5), the exact 160 KiB LDS fit (d = 128, K = 32), tables staged in
+# 2 and 4 pieces per step (K = 40, 100), dpad < 128, ragged batches that leave waves and whole rounds without a tile.
+SHARED = [(128, 5, 1000), (128, 16, 4096 + 7), (128, 24, 300), (128, 32, 33000), (128, 40, 200), (128, 100, 40000), (40, 6, 2500),
+          (16, 48, 70000), (64, 64, 9), (100, 70, 600)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,B", SHARED)
+def test_shared_mixture_table(gpu, d, K, B):
+    N, p0, pb = 12, max(0, B // 2 - 8), min(B, 24)
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=d + K)
+    loss.seed = 11
+    x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw) if B >= 64 else loss.simulate(ts, x0, *args, **kw)
+    sde = orc.VP(0.1, 10.0, 1.0, 1.0)
+    tgt = orc.GMMDiag(info["target"].loc.cpu(), info["target"].scale.cpu(), info["target"].mixture_weights.cpu())
+    ctrl = orc.Ctrl(_sd(info["ctrl"]), "clipped", clip_model=1e4)
+    means, var, w = info["means"].cpu(), 0.5 * torch.ones(K, d), torch.ones(K)
+    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+    refd = orc.GMMDiag(loc0, v0.sqrt(), w)
+    with torch.no_grad():
+        ox, ornd, _ = orc.simulate_ei_ref(ts.cpu(), x0[p0:p0 + pb].cpu(), ctrl, sde, tgt.logp, refd.logp,
+                                          lambda t, xx: orc.mog_score(xx, w, *sde.marginal_diag(t, means, var)),
+                                          orc.PhiloxNoise(11, particle0=p0))
+    x_err = gc.rel_err(x[p0:p0 + pb].cpu(), ox)
+    r_err = _rnd_err(rnd[p0:p0 + pb], ornd, max(1.0, float(tgt.logp(ox).abs().max())))
+    print(f"shared table d={d} K={K} B={B}: x_N {x_err:.2e}, rnd {r_err:.2e}")
+    assert x_err < 2e-4 and r_err < 2e-4
+
+
 # ---- every kernel family at full occupancy --------------------------------------------------------------------------
 # The golden cases replicated to 32 768+ particles (each replica draws its own Philox noise): reruns and shards must be
 # bit-identical, and blocks of the big run -- chosen so that every wave slot of a workgroup is covered -- must equal a

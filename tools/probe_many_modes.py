@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from sde_sampler_lrds_amd import _lib as L
 from sde_sampler_lrds_amd.experiments.baseline_configs import build_rds_gmm
 dev = torch.device("cuda:0")
-for K in (16, 64):
+for K in (8, 16, 24, 32, 64):
     loss, ts, x0, args, _, info = build_rds_gmm(dev, 65536, 256, K=K)
     ev = L.HipEvents(); loss.timing_events = ev
     for rep in range(3):
