@@ -172,6 +172,12 @@ def main():
     out = None
     if rank == 0:
         achieved = flops_ps * B * N / (k_ms * 1e-3) / 1e12
+        # HBM bytes per launch cannot be counted from inside this process: the figure is the committed rocprofv3 PMC
+        # measurement of this same workload (tools/pmc_passes.sh), reported only when the workload is the one measured
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_pmc_cfg2_traffic.json")
+        if os.path.exists(tj) and (B, N, a.modes) == (65536, 256, 4):
+            traffic, traffic_src = json.load(open(tj))["bytes"], "profiles/r01_pmc_cfg2_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
         out = {
             "metric": "particle-steps/sec (batch*n_steps/wall)", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps,
@@ -181,7 +187,8 @@ def main():
                        "particles_per_gpu": B, "sde_steps": N, "parallelism": f"particle-sharded x{world}"},
             "log_norm_const_is": res["log_norm_const_is"], "ess": res["ess"], "spinup_s": a.spinup,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "algorithmic_hbm_bytes_per_launch": (2 * 128 + 1) * 4 * B,
                          "kernel": "k_simulate<NT=8,REF=GMM,SC=NONE,FORM=LIN> (one launch = all sde_steps of the batch)",
                          "kernel_ms": k_ms, "algorithmic_flops_per_particle_step": flops_ps,
                          "note": "peak = dense FP32 MFMA/vector rate: results carry fp32 accuracy; the GEMMs are issued as a "

@@ -134,6 +134,12 @@ __global__ void __launch_bounds__(128) k_ref_tables(RefTabArgs a) {
     cs[0] = 0.5f * red[0];
     cs[1] = logf(w);
   }
+  if (blockIdx.x == 0) {  // do all components share one variance vector?  (bitwise: the shortcut it enables is exact algebra)
+    int differ = 0;
+    for (int i = threadIdx.x; i < a.K * a.d; i += 128) differ |= a.vars[i] != a.vars[i % a.d];
+    differ = __syncthreads_or(differ);
+    if (threadIdx.x == 0) a.same_var[0] = differ ? 0.0f : 1.0f;
+  }
 }
 
 // static tables of a diagonal Gaussian / mixture: tab[c][0][f] = loc, tab[c][1][f] = 1/scale^2;

@@ -27,6 +27,7 @@ struct RefTabArgs {
   const float *means, *vars, *weights;
   float* tab;     // [N][K][2][dpad]
   float* consts;  // [N][K][2]
+  float* same_var;  // [1]: 1.0 when every component has the same variance vector (then so has every noised marginal)
 };
 
 struct DistTabArgs {

@@ -105,7 +105,7 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.stheta = o; o += align64(d->N + 1);
   const int K = d->ref.kind == SDENG_REF_NONE ? 0 : (d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k);
   L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * K * 2 * dpad);
-  L.ref_consts = o; o += align64(static_cast<size_t>(d->N) * K * 2);
+  L.ref_consts = o; o += align64(static_cast<size_t>(d->N) * K * 2 + 1);  // + the shared-variance flag
   L.target = o; o += dist_floats(d->target, dpad);
   L.ref_dist = o; o += dist_floats(d->ref_dist, dpad);
   L.prior = o; o += dist_floats(d->prior, dpad);
@@ -383,6 +383,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
       r.K = K; r.d = d->d; r.dpad = dpad; r.coef = d->coef;
       r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = rf != RF_GAUSS ? d->ref.weights : nullptr;
       r.tab = ws + L.ref_tab; r.consts = ws + L.ref_consts;
+      r.same_var = ws + L.ref_consts + static_cast<size_t>(d->N) * K * 2;
       SD_HIP(sd_launch_ref_tables(r, d->N, s));
     }
     a.ref_k = K;
@@ -403,6 +404,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
       }
     }
     a.ref_tab = ws + L.ref_tab; a.ref_consts = ws + L.ref_consts;
+    a.ref_same_var = ws + L.ref_consts + static_cast<size_t>(d->N) * K * 2;
     a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
   } else if (d->ref.kind != SDENG_REF_NONE) {
     return fail(SDENG_E_UNSUPPORTED, "reference kind %d", d->ref.kind);

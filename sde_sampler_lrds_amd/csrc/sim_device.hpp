@@ -480,6 +480,26 @@ SD_INLINE f32x4 gmm_score_tile(const f32x4 (&x)[NT], const float* __restrict__ t
   return acc;
 }
 
+// The same when every component has the same variance vector (the reference's default initialisation, and then
+// true of every noised marginal): sum_k p_k (m_k - x)/var = (sum_k p_k m_k - x)/var, one fma per component and element.
+template <int NT>
+SD_INLINE f32x4 gmm_score_tile_shared_var(const f32x4 (&x)[NT], const float* __restrict__ tab, int K, int g, const float (&p)[SD_KREG], int t) {
+  constexpr int dpad = 16 * NT;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) {
+    if (k < K) {
+      const f32x4 m = load_tile4(tab + static_cast<size_t>(k) * 2 * dpad, t, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(p[k], m[r], acc[r]);
+    }
+  }
+  const f32x4 iv = load_tile4(tab + dpad, t, g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (acc[r] - x[t][r]) * iv[r];
+  return acc;
+}
+
 // Gaussian (one component) score of one tile: -(x - mean)/var  (distr/gauss.py:124-126)
 template <int NT>
 SD_INLINE f32x4 gauss_score_tile(const f32x4 (&x)[NT], const float* __restrict__ tab, int g, int t) {

@@ -74,6 +74,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   static_assert(!eubo || (SC == SC_NONE) != (REF == RF_NONE), "EUBO kernels: reference-SDE losses with a ClippedCtrl, or DIS (no reference)");
   const bool full_d = a.d == dpad;
   float* trash = a.trash + tid * 4;
+  bool same_var = false;
+  if constexpr (REF == RF_GMM) same_var = a.N > 0 && a.ref_same_var[0] != 0.0f;
 
   // CUs first; shared-table mode: the round's wave-0 tile decides, so all 8 waves run the same rounds
   for (int tile = blockIdx.x + gridDim.x * wave; (share ? tile - static_cast<int>(gridDim.x) * wave : tile) < a.ntiles;
@@ -227,7 +229,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 #ifdef SD_DBG_NOREF
           if constexpr (REF == RF_GMM) rq = f32x4{resp[0], resp[0], resp[0], resp[0]};
 #else
-          if constexpr (REF == RF_GMM) rq = gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
+          if constexpr (REF == RF_GMM)
+            rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
 #endif
           if constexpr (REF == RF_GMM_BIG) rq = rs[t];
           if constexpr (REF == RF_GAUSS) rq = gauss_score_tile<NT>(x, rtab, g, t);

@@ -175,3 +175,33 @@ def test_empty_batch_and_bad_descriptor(gpu):
     b["loss"].reference_ctrl = lambda t, x: x  # opaque callable
     with pytest.raises(E.UnsupportedByEngine):
         b["loss"].simulate(b["ts"], b["x0"], *b["args"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,B", [(128, 4, 48), (20, 3, 37), (16, 2, 16)])
+def test_shared_variance_reference_matches_oracle(gpu, d, K, B):
+    """Mixture references whose components share one variance vector (the reference's default initialisation,
+    solver/oc.py:563-576 with variances_init = const) take the (sum_k p_k m_k - x)/var form of the score in the step
+    loop (detected on the device by k_ref_tables); the fixtures all have distinct variances, so this case is checked
+    against the oracle directly, under identical injected noise, at the fixtures' tolerance."""
+    from oracle import sde_oracle as orc
+    from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
+    N = 24
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=100 + d)
+    z = torch.randn(N, B, d, generator=torch.Generator().manual_seed(d))
+    x, rnd, _ = loss.simulate(ts, x0, *args, noise=z.to(gpu), **kw)
+    sde = orc.VP(0.1, 10.0, 1.0, 1.0)
+    tgt = orc.GMMDiag(info["target"].loc.cpu(), info["target"].scale.cpu(), info["target"].mixture_weights.cpu())
+    sd = {k: v.detach().cpu() for k, v in info["ctrl"].state_dict().items()}
+    ctrl = orc.Ctrl(sd, "clipped", clip_model=1e4)
+    means, var, w = info["means"].cpu(), 0.5 * torch.ones(K, d), torch.ones(K)
+    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+    refd = orc.GMMDiag(loc0, v0.sqrt(), w)
+    with torch.no_grad():
+        ox, ornd, _ = orc.simulate_ei_ref(ts.cpu(), x0.cpu(), ctrl, sde, tgt.logp, refd.logp,
+                                          lambda t, xx: orc.mog_score(xx, w, *sde.marginal_diag(t, means, var)), orc.InjectedNoise(z))
+    # log-weight error relative to the largest summand (the terminal log-densities), as rnd_scale() above
+    scale = torch.stack([ornd.flatten().abs(), tgt.logp(ox).flatten().abs(), refd.logp(ox).flatten().abs()]).max(dim=0).values.clamp(min=1.0)
+    ex, er = gc.rel_err(x.cpu(), ox), float(((rnd.cpu().flatten() - ornd.flatten()).abs() / scale).max())
+    print(f"shared-variance reference d={d} K={K}: x_N {ex:.2e}, rnd {er:.2e}")
+    assert ex < TOL and er < TOL
