@@ -116,6 +116,12 @@ typedef struct sdeng_dist {
 #define SDENG_CTRL_CLIPPED 0
 #define SDENG_CTRL_SCORE 1
 #define SDENG_CTRL_LERP 2
+/* no drift net: EulerIntegrator.integrate (eq/integrator.py:93-129) of an uncontrolled linear SDE (OU.drift/diff,
+ * eq/sdes.py:143-148; the inference process of solver/oc.py:162-180) or of the classic Langevin SDE (LangevinSDE,
+ * eq/sdes.py:46-76; solver/langevin.py:36-66).  form = SDENG_FORM_EM, no reference; per step
+ *   x' = x + (coef[1] x + clip(coef[7] score_target(x), net.clip_score)) coef[4] + coef[2] (z coef[5])
+ * (target.kind NONE: no score term).  rnd_out is zero-filled; xs_out carries the N+1 states. */
+#define SDENG_CTRL_NONE 3
 #define SDENG_HIDDEN 64
 
 typedef struct sdeng_time_embed { /* models/mlp.py:57-96 TimeEmbed */

@@ -889,6 +889,47 @@ def simulate_cmcd(ts, x, ctrl, target_score, prior_score, g, T, clip_score, term
 # --------------------------------------------------------------------------- #
 # estimators -- losses/oc.py:134-173, eval/metrics.py:135-140
 # --------------------------------------------------------------------------- #
+# --------------------------------------------------------------------------- #
+# eq/integrator.py -- EulerIntegrator
+# --------------------------------------------------------------------------- #
+def langevin_sde_drift(x, target_score, g, clip_score=None):
+    """eq/sdes.py:63-71 LangevinSDE.drift: clip(score * g^2 / 2)."""
+    return clip(target_score(x) * g ** 2 / 2.0, clip_score)
+
+
+def euler_integrate(drift, diff, ts, x_init, timesteps, increment, eps=1e-8):
+    """eq/integrator.py:93-129 EulerIntegrator.integrate with explicit ``timesteps``.
+
+    ``drift(s, x)`` / ``diff(s)`` are the SDE's coefficient functions, ``increment(k, s, t, x)`` the Brownian increment of
+    step k (the reference: ``randn * sqrt(t - s)`` :115, or ``bm(s, t)`` :117).  Returns the states interpolated onto
+    ``ts`` (:119-122 with ``interpolate`` :66-77)."""
+    ts_count, out, xs = 0, [], x_init
+    for k, (s, t) in enumerate(zip(timesteps[:-1], timesteps[1:])):
+        noise = increment(k, s, t, xs)
+        xt = xs + drift(s, xs) * (t - s) + diff(s) * noise  # :118
+        if ts[ts_count] <= t + eps:  # :120
+            rest = ts[ts_count:]
+            ind = torch.searchsorted(rest, t + eps, side="right")  # :73
+            t_eval = rest[:ind]
+            assert (s <= t_eval).all() and (t_eval <= t + eps).all()  # :75
+            out.append(torch.lerp(xs, xt, (t_eval.view(-1, 1, 1) - s) / (t - s)))  # :76
+            ts_count += out[-1].shape[0]
+        xs = xt
+    out = torch.cat(out)
+    assert ts_count == out.shape[0]  # :128
+    return out
+
+
+def controlled_sde_drift(sde, ctrl):
+    """eq/sdes.py:709-720 ControlledSDE.f_and_g: sde.drift(t, x) + sde.diff(t) * ctrl(T - t, x)."""
+    def drift(t, x):
+        out = sde.drift(t, x)
+        if ctrl is not None:
+            out = out + sde.diff(t) * ctrl(sde.T - t, x)
+        return out
+    return drift
+
+
 def compute_results(rnd: torch.Tensor) -> dict:
     neg = -rnd
     w = torch.softmax(neg, dim=0)

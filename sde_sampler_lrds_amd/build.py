@@ -41,7 +41,8 @@ DTS, REFS, SCS, FORMS = (1, 2, 4, 8), (0, 1, 2, 3), (0, 1, 2), (0, 1)  # DTS: fe
 
 def sources():
     os.makedirs(GEN, exist_ok=True)
-    srcs = [os.path.join(CSRC, "sdeng_api.hip"), os.path.join(CSRC, "prep_kernels.hip"), os.path.join(CSRC, "cmcd_inst.hip")]
+    srcs = [os.path.join(CSRC, "sdeng_api.hip"), os.path.join(CSRC, "prep_kernels.hip"), os.path.join(CSRC, "cmcd_inst.hip"),
+            os.path.join(CSRC, "euler_inst.hip")]
     for dt in DTS:  # CMCD kernels (3 target kinds each)
         path = os.path.join(GEN, f"cmcd_{dt}.hip")
         _write_if_changed(path, '#include "../cmcd_kernel.hpp"\n'

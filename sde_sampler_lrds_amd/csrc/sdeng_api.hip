@@ -336,6 +336,40 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   return 0;
 }
 
+int sd_launch_euler_1(const SimArgs& a, int sc, hipStream_t s);
+int sd_launch_euler_2(const SimArgs& a, int sc, hipStream_t s);
+int sd_launch_euler_4(const SimArgs& a, int sc, hipStream_t s);
+int sd_launch_euler_8(const SimArgs& a, int sc, hipStream_t s);
+
+// SDENG_CTRL_NONE: Euler-Maruyama of an SDE without a drift net (euler_kernel.hpp)
+static int simulate_euler(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s) {
+  if (d->form != SDENG_FORM_EM) return fail(SDENG_E_UNSUPPORTED, "CTRL_NONE (no drift net) runs the Euler-Maruyama form only (form %d given)", d->form);
+  if (d->ref.kind != SDENG_REF_NONE) return fail(SDENG_E_UNSUPPORTED, "CTRL_NONE with a reference drift");
+  if (d->flags & (SDENG_FLAG_TERM_REF | SDENG_FLAG_TERM_TARGET | SDENG_FLAG_INIT_LOGP))
+    return fail(SDENG_E_UNSUPPORTED, "CTRL_NONE carries no log-weight: terminal / initial cost flags are not accepted");
+  const int dpad = 16 * DT;
+  int sc = SC_NONE;
+  DistDev target;
+  int rc = build_dist(d->target, d->d, dpad, ws + L.target, target, s);
+  if (rc) return rc;
+  if (d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_RINGS) sc = SC_GMM;
+  else if (d->target.kind == SDENG_DIST_PHI4) sc = SC_PHI4;
+  else if (d->target.kind != SDENG_DIST_NONE)
+    return fail(SDENG_E_UNSUPPORTED, "Langevin drift: no in-loop score kernel for target kind %d", d->target.kind);
+  a.target = target;
+  a.clip_score = d->net.clip_score;
+  if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
+  switch (DT) {
+    case 1: rc = sd_launch_euler_1(a, sc, s); break;
+    case 2: rc = sd_launch_euler_2(a, sc, s); break;
+    case 4: rc = sd_launch_euler_4(a, sc, s); break;
+    default: rc = sd_launch_euler_8(a, sc, s); break;
+  }
+  SD_HIP(rc);
+  if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
+  return 0;
+}
+
 extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!d) return fail(SDENG_E_INVALID, "null descriptor");
@@ -366,6 +400,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   a.ntiles = (d->B + 15) / 16;
 
   if (d->form == SDENG_FORM_CMCD || d->form == SDENG_FORM_CMCD_EUBO) return simulate_cmcd(d, L, ws, DT, a, s);
+  if (d->net.ctrl_kind == SDENG_CTRL_NONE) return simulate_euler(d, L, ws, DT, a, s);
   int rc = prepare_net(d, L, ws, DT, a, s, d->N, false, 0.0f);
   if (rc) return rc;
   int sc;

@@ -7,6 +7,15 @@ from __future__ import annotations
 import torch
 
 
+# distr/base.py:13-18
+EXPECTATION_FNS = {
+    "square": lambda x: (x ** 2).sum(dim=-1, keepdims=True),
+    "abs": lambda x: x.abs().sum(dim=-1, keepdims=True),
+    "sum": lambda x: x.sum(dim=-1, keepdims=True),
+    "square_minus_sum": lambda x: (x ** 2 - x).sum(dim=-1, keepdims=True),
+}
+
+
 class Distribution(torch.nn.Module):
     def __init__(self, dim: int, log_norm_const: float | None = None, domain=None, n_reference_samples=None,
                  grid_points=None, **kwargs):

@@ -434,6 +434,64 @@ def run(desc: L.Desc, x: torch.Tensor, keep: list, return_traj=False, noise=None
     return x_out, rnd, xs
 
 
+def euler_states(sde, timesteps: torch.Tensor, x: torch.Tensor, increments=None, seed: int = 0, particle0: int = 0, events=None):
+    """All N+1 Euler-Maruyama states ``[N+1, B, d]`` of ``sde`` on the grid ``timesteps`` in one launch
+    (the loop of EulerIntegrator.integrate, eq/integrator.py:113-122: ``xt = xs + drift(s, xs) (t-s) + diff(s, xs) noise``).
+
+    * ``LangevinSDE`` (eq/sdes.py:46-76) and uncontrolled ``OU`` SDEs / ``ControlledSDE(sde, None)`` run the net-free kernel
+      (SDENG_CTRL_NONE);
+    * ``ControlledSDE(sde, ctrl)`` (eq/sdes.py:681-720; the net is evaluated at ``T - s``) runs the step-loop kernel.
+    ``increments`` ``[N,B,d]`` replays Brownian increments (the reference's ``bm(s, t)``); otherwise Philox normals times sqrt(dt).
+    """
+    require_gpu(x)
+    device, keep = x.device, []
+    ts = timesteps.detach().to("cpu", torch.float32)
+    N = ts.numel() - 1
+    desc = L.Desc()
+    desc.form, desc.flags, desc.N = L.FORM_EM, 0, N
+    desc.seed, desc.particle0 = int(seed), int(particle0)
+    coef = torch.zeros(N, L.NCOEF, dtype=torch.float32)
+    name = _name(sde)
+    ctrl = getattr(sde, "ctrl", None) if name == "ControlledSDE" else None
+    if name == "LangevinSDE":
+        tgt = _self_of(sde.target_score)
+        if tgt is None:
+            raise UnsupportedByEngine("LangevinSDE.target_score must be a bound Distribution.score")
+        desc.target = dist_desc(tgt, device, keep)
+        desc.net.ctrl_kind = L.CTRL_NONE
+        desc.net.clip_score = float(sde.clip_score) if sde.clip_score else 0.0
+        g = sde.diff_coeff.detach().float().cpu()
+        coef[:, 2], coef[:, 7] = g, g ** 2 / 2.0  # eq/sdes.py:65
+    else:
+        base = _cpu_sde(sde.sde if name == "ControlledSDE" else sde)
+        if not hasattr(base, "drift_coeff_t"):
+            raise UnsupportedByEngine(f"EulerIntegrator: no HIP kernel for SDE {name}")
+        T = base.terminal_t
+        if ctrl is None:
+            desc.net.ctrl_kind = L.CTRL_NONE
+        else:
+            desc.net = net_desc(ctrl, device, keep)
+            tgt, lerp_prior = ctrl_target(ctrl)
+            if tgt is not None:
+                desc.target = dist_desc(tgt, device, keep)
+            if lerp_prior is not None:
+                desc.prior = dist_desc(lerp_prior, device, keep)
+        for k in range(N):
+            s = ts[k]
+            g = base.diff(s, None)
+            coef[k, 0], coef[k, 1], coef[k, 2], coef[k, 3] = T - s, base.drift_coeff_t(s), g, torch.square(g)
+            if ctrl is not None and _name(ctrl) == "LerpCtrl":  # reparam.py:175, :199 at the net's time T - s
+                coef[k, 7], coef[k, 8] = base.diff(T - s, None), (T - s) / T
+    dt = ts[1:] - ts[:-1]
+    coef[:, 4] = dt
+    coef[:, 5] = 1.0 if increments is not None else dt.sqrt()
+    coef = coef.to(device)
+    keep.append(coef)
+    desc.coef = coef.data_ptr()
+    _, _, xs = run(desc, x, keep, return_traj=True, noise=increments, events=events)
+    return xs
+
+
 def philox_noise(seed: int, N: int, B: int, d: int, particle0: int, device) -> torch.Tensor:
     """[N,B,d] normals of the step loop's counter-based stream (the kernel draws exactly these when no noise is injected)."""
     lib = L.lib()

@@ -25,6 +25,33 @@ class TorchSDE(Module):
         _buf(self, "terminal_t", terminal_t)
 
 
+class LangevinSDE(TorchSDE):
+    """Classic Langevin SDE (eq/sdes.py:46-76): drift = clip(score_pi(x) g^2 / 2), diffusion g."""
+
+    def __init__(self, target_score: Callable, diff_coeff: float = 1.0, clip_score=None, **kw):
+        super().__init__(**kw)
+        self.target_score, self.clip_score = target_score, clip_score
+        _buf(self, "diff_coeff", diff_coeff)
+
+    def drift(self, t, x):
+        out = self.target_score(x) * self.diff_coeff ** 2 / 2.0
+        return out if self.clip_score is None else out.clip(-self.clip_score, self.clip_score)
+
+    def diff(self, t, x=None):
+        return self.diff_coeff
+
+
+class ControlledSDE(TorchSDE):
+    """OU SDE plus a control (eq/sdes.py:681-720): drift = sde.drift(t, x) + sde.diff(t) ctrl(T - t, x)."""
+
+    def __init__(self, sde, ctrl, **kw):
+        super().__init__(terminal_t=float(sde.terminal_t), **kw)
+        self.sde, self.ctrl = sde, ctrl
+
+    def diff(self, t, x=None):
+        return self.sde.diff(t, x)
+
+
 class ControlledLangevinSDE(TorchSDE):
     """Annealed-Langevin path of CMCD: drift = 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T))."""
 

@@ -11,7 +11,7 @@ from sde_sampler_lrds_amd.distr.gauss import GMM, Gauss, GaussFull, IsotropicGau
 from sde_sampler_lrds_amd.distr.logistic_regression import LogisticRegression
 from sde_sampler_lrds_amd.distr.phi_four import PhiFour
 from sde_sampler_lrds_amd.distr.rings import Rings
-from sde_sampler_lrds_amd.eq.sdes import VP, ControlledLangevinSDE, PinnedBM, ScaledBM
+from sde_sampler_lrds_amd.eq.sdes import VP, ControlledLangevinSDE, ControlledSDE, LangevinSDE, PinnedBM, ScaledBM
 from sde_sampler_lrds_amd.losses import oc
 from sde_sampler_lrds_amd.models.mlp import FourierMLP, TimeEmbed
 from sde_sampler_lrds_amd.models.reparam import ClippedCtrl, LerpCtrl, ScoreCtrl
@@ -159,3 +159,24 @@ def build(c, device):
     out["x0"] = c["x0"].to(device)
     out["loss"].seed = m["seed"]
     return out
+
+
+def build_euler(c, device):
+    """The SDE object of an Euler fixture (tests/golden/gen_golden.py:case_euler) from the product classes."""
+    m, d, kind = c.meta, c.meta["d"], c.meta["sde_kind"]
+    if kind.startswith("langevin"):
+        if kind == "langevin_gmm":
+            target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
+        elif kind == "langevin_phi4":
+            target = PhiFour(a=m["phi_a"], b=m["phi_b"], dim=d, beta=m["phi_beta"])
+        else:
+            target = Rings(dim=2, lower_rad=m["lower_rad"], upper_rad=m["upper_rad"], num_rad=m["num_rad"], scale=m["scale"],
+                           n_reference_samples=10)
+        target = target.to(device)
+        return LangevinSDE(target_score=target.score, diff_coeff=m["diff_coeff"], clip_score=m["clip_score"], terminal_t=m["T"]).to(device)
+    base = make_sde(m).to(device)
+    if kind == "controlled_vp":
+        ctrl = ClippedCtrl(base_model=_mlp(d), clip_model=m["clip_model"])
+        ctrl.load_state_dict(c.params("ctrl."))
+        return ControlledSDE(sde=base, ctrl=ctrl.to(device))
+    return base

@@ -49,6 +49,7 @@ from sde_sampler.distr import gauss as r_gauss  # noqa: E402
 from sde_sampler.distr import logistic_regression as r_lr  # noqa: E402
 from sde_sampler.distr import phi_four as r_phi  # noqa: E402
 from sde_sampler.distr import rings as r_rings  # noqa: E402
+from sde_sampler.eq import integrator as r_int  # noqa: E402
 from sde_sampler.eq import sdes as r_sdes  # noqa: E402
 from sde_sampler.losses import oc as r_oc  # noqa: E402
 from sde_sampler.models import mlp as r_mlp  # noqa: E402
@@ -766,6 +767,61 @@ def unit_vectors():
     save("unit_vectors", dict(kind="unit", **meta), out)
 
 
+def case_euler(name, kind, d, B, N, seed, n_out=7):
+    """EulerIntegrator.integrate (eq/integrator.py:93-129) on the SDEs the solvers hand it:
+    ``langevin_*``: LangevinSDE of a target (eq/sdes.py:46-76; solver/langevin.py:36-66); ``ou_vp``: the uncontrolled
+    inference process (solver/oc.py:162-180, :502); ``controlled_vp``: ControlledSDE(VP, ClippedCtrl) (solver/oc.py:205, :378).
+    The Brownian increments come through the integrator's own ``bm`` hook: bm(s_k, t_k) = philox_normal(seed, k) sqrt(t_k - s_k).
+    The grid is non-uniform and ``ts`` (n_out points) is coarser than it, so the interpolation (:66-77, :120-122) is exercised."""
+    torch.manual_seed(seed)
+    T = 1.0
+    meta = dict(kind="euler", sde_kind=kind, d=d, B=B, N=N, seed=seed, T=T)
+    arrays = {}
+    if kind.startswith("langevin"):
+        g, clip_score = 1.3, 40.0
+        if kind == "langevin_gmm":
+            target = r_gauss.ManyModes(n_modes=4, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
+            arrays.update(tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
+        elif kind == "langevin_phi4":
+            target = r_phi.PhiFour(a=0.1, b=0.0, dim=d, dim_phys=1, beta=20.0)
+            meta.update(phi_a=0.1, phi_b=0.0, phi_beta=20.0)
+            T, g = 0.05, 1.0
+        else:
+            target = r_rings.Rings(dim=2, n_reference_samples=10)
+            meta.update(lower_rad=1.0, upper_rad=5.0, num_rad=3, scale=0.1)
+            arrays.update(rings_rad=target.radiuses, rings_w=target.radius_dist.mixture_distribution.probs)
+            T, g, clip_score = 0.5, 1.0, 25.0
+        sde = r_sdes.LangevinSDE(target_score=target.score, diff_coeff=g, clip_score=clip_score, terminal_t=T)
+        meta.update(diff_coeff=g, clip_score=clip_score, T=T)
+    else:
+        base = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=T)
+        meta.update(sde="vp", beta_min=0.1, beta_max=10.0, sigma=1.0)
+        if kind == "controlled_vp":
+            ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
+            sde = r_sdes.ControlledSDE(sde=base, ctrl=ctrl)
+            meta.update(clip_model=1e4)
+            arrays.update(pack_params("ctrl.", sd(ctrl)))
+        else:
+            sde = base
+    inner = torch.sort(torch.rand(N - 1) * T).values
+    timesteps = torch.cat([torch.zeros(1), inner, torch.tensor([T])]).float()
+    ts = torch.linspace(0.0, T, n_out)
+    x0 = (0.3 if kind == "langevin_phi4" else 1.5) * orc.philox_normal(seed, 0, 0, B, d, stream=1)
+    grid = [float(v) for v in timesteps]
+
+    def bm(s, t):
+        k = grid.index(float(s))
+        return orc.philox_normal(seed, k, 0, B, d) * torch.sqrt(t - s)
+
+    with torch.no_grad():
+        out = r_int.EulerIntegrator().integrate(sde, ts=ts, x_init=x0.clone(), timesteps=timesteps, bm=bm)
+        full = r_int.EulerIntegrator().integrate(sde, ts=timesteps, x_init=x0.clone(), timesteps=timesteps, bm=bm)
+    assert out.shape == (n_out, B, d) and bool(torch.isfinite(out).all())
+    arrays.update(ts=ts, timesteps=timesteps, x0=x0, out_xs=out, out_last=full[-1])
+    save(name, meta, arrays)
+    print(f"   |x_T| max {float(full[-1].abs().max()):.3f}")
+
+
 CASES = {
     "unit_vectors": unit_vectors,
     # config 2 family (ManyModes d=128, RDS gmm-ref, VP, EI)
@@ -804,6 +860,12 @@ CASES = {
     "cmcd_phi4_d100": lambda n: case_cmcd_phi4(n, d=100, B=16, N=256, seed=44),
     "pis_logreg_d61": lambda n: case_logreg_ctrl(n, B=32, N=32, seed=45, solver="pis"),
     "dds_logreg_d61": lambda n: case_logreg_ctrl(n, B=32, N=32, seed=46, solver="dds"),
+    # EulerIntegrator (eq/integrator.py) on Langevin / uncontrolled / controlled SDEs
+    "euler_langevin_gmm_d16": lambda n: case_euler(n, "langevin_gmm", d=16, B=48, N=40, seed=81),
+    "euler_langevin_phi4_d100": lambda n: case_euler(n, "langevin_phi4", d=100, B=24, N=32, seed=82),
+    "euler_langevin_rings_d2": lambda n: case_euler(n, "langevin_rings", d=2, B=96, N=48, seed=83),
+    "euler_ou_vp_d40": lambda n: case_euler(n, "ou_vp", d=40, B=32, N=24, seed=84),
+    "euler_controlled_vp_d16": lambda n: case_euler(n, "controlled_vp", d=16, B=48, N=32, seed=85),
     # DIS variants
     "dis_ei_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=51, kind="ei"),
     "dis_orig_lerp_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=64, seed=52, kind="orig"),

@@ -25,6 +25,10 @@ SIM_CASES = [
 EUBO_CASES = ["eubo_ei_gmm_d128_k4", "eubo_ei_gmm_d16_k4", "eubo_em_gmm_d16_k4", "eubo_dis_ei_d8", "eubo_cmcd_gmm_d16"]  # compute_eubo (noising direction)
 
 
+EULER_CASES = ["euler_langevin_gmm_d16", "euler_langevin_phi4_d100", "euler_langevin_rings_d2", "euler_ou_vp_d40",
+               "euler_controlled_vp_d16"]  # EulerIntegrator.integrate (eq/integrator.py)
+
+
 class Case:
     def __init__(self, name):
         z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
@@ -185,3 +189,31 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a-b| / max(1, |b|) elementwise-scaled: relative for large values, absolute near zero."""
     a, b = a.double(), b.double()
     return float(((a - b).abs() / b.abs().clamp(min=1.0)).max())
+
+
+def euler_increment(c: Case):
+    """The Brownian increments an Euler fixture was generated with: bm(s_k, t_k) = philox_normal(seed, k) sqrt(t_k - s_k)."""
+    m = c.meta
+    return lambda k, s, t, x: orc.philox_normal(m["seed"], k, 0, x.shape[0], x.shape[1]) * torch.sqrt(t - s)
+
+
+def run_oracle_euler(c: Case, ts=None, increment=None):
+    """Oracle restatement of EulerIntegrator.integrate for an Euler case -> states on ``ts`` (default: the fixture's)."""
+    m = c.meta
+    kind = m["sde_kind"]
+    if kind.startswith("langevin"):
+        if kind == "langevin_gmm":
+            tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
+        elif kind == "langevin_phi4":
+            tgt = orc.PhiFour(m["phi_a"], m["phi_b"], m["d"], m["phi_beta"])
+        else:
+            tgt = orc.Rings(m["lower_rad"], m["upper_rad"], m["num_rad"], m["scale"])
+        g = torch.tensor(m["diff_coeff"], dtype=torch.float32)
+        drift = lambda s, x: orc.langevin_sde_drift(x, tgt.score, g, m["clip_score"])  # noqa: E731
+        diff = lambda s: g  # noqa: E731
+    else:
+        sde = make_sde(m)
+        ctrl = orc.Ctrl(c.params("ctrl."), "clipped", clip_model=m["clip_model"]) if kind == "controlled_vp" else None
+        drift, diff = orc.controlled_sde_drift(sde, ctrl), sde.diff
+    with torch.no_grad():
+        return orc.euler_integrate(drift, diff, c["ts"] if ts is None else ts, c["x0"], c["timesteps"], increment or euler_increment(c))

@@ -205,3 +205,60 @@ def test_shared_variance_reference_matches_oracle(gpu, d, K, B):
     ex, er = gc.rel_err(x.cpu(), ox), float(((rnd.cpu().flatten() - ornd.flatten()).abs() / scale).max())
     print(f"shared-variance reference d={d} K={K}: x_N {ex:.2e}, rnd {er:.2e}")
     assert ex < TOL and er < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", gc.EULER_CASES)
+def test_euler_integrator_matches_reference_fixture(gpu, name):
+    """EulerIntegrator.integrate (one launch + interpolation) against the reference's own output under identical Brownian
+    increments (through the integrator's ``bm`` hook), then with the kernel's Philox stream against the oracle."""
+    from sde_sampler_lrds_amd.eq.integrator import EulerIntegrator
+    c = gc.load(name)
+    m = c.meta
+    sde = bc.build_euler(c, gpu)
+    grid_cpu = c["timesteps"]
+    incs = torch.stack([orc.philox_normal(m["seed"], k, 0, m["B"], m["d"]) * torch.sqrt(grid_cpu[k + 1] - grid_cpu[k])
+                        for k in range(m["N"])]).to(gpu)
+    index = {float(v): k for k, v in enumerate(grid_cpu[:-1])}
+    out = EulerIntegrator().integrate(sde, ts=c["ts"].to(gpu), x_init=c["x0"].to(gpu), timesteps=grid_cpu.to(gpu),
+                                      bm=lambda s, t: incs[index[float(s)]])
+    err = gc.rel_err(out.cpu(), c["out_xs"])
+    full = EulerIntegrator().integrate(sde, ts=grid_cpu.to(gpu), x_init=c["x0"].to(gpu), timesteps=grid_cpu.to(gpu),
+                                       bm=lambda s, t: incs[index[float(s)]])
+    err_last = gc.rel_err(full[-1].cpu(), c["out_last"])
+    print(f"{name}: injected increments: interpolated states {err:.2e}, x_T {err_last:.2e}")
+    assert out.shape == c["out_xs"].shape and err < TOL and err_last < TOL
+    assert torch.equal(full[0].cpu(), c["x0"])
+    # Philox mode: the kernel's own stream (first call of an integrator with seed 5) vs the oracle's definition of it
+    got = EulerIntegrator(seed=5).integrate(sde, ts=c["ts"].to(gpu), x_init=c["x0"].to(gpu), timesteps=grid_cpu.to(gpu))
+    want = gc.run_oracle_euler(c, increment=lambda k, s, t, x: orc.philox_normal(5, k, 0, x.shape[0], x.shape[1]) * torch.sqrt(t - s))
+    err_p = gc.rel_err(got.cpu(), want)
+    print(f"{name}: philox mode {err_p:.2e}")
+    assert err_p < 1e-4
+
+
+@pytest.mark.gpu
+def test_langevin_solver_reaches_the_target(gpu):
+    """solver/langevin.py:36-66 on the engine: with diff_coeff = sqrt(2) the Langevin SDE is stationary at the target; a
+    one-component Gaussian target is reached from a wide prior (mean / variance within Monte-Carlo error + O(dt) bias)."""
+    from functools import partial
+
+    from sde_sampler_lrds_amd.distr.gauss import GMM, IsotropicGauss
+    from sde_sampler_lrds_amd.eq.integrator import EulerIntegrator
+    from sde_sampler_lrds_amd.solver.langevin import LangevinSolver
+    from sde_sampler_lrds_amd.utils.common import get_timesteps
+    d = 6
+    loc, scale = torch.linspace(-2.0, 2.0, d).view(1, d), torch.linspace(0.5, 1.0, d).view(1, d)
+    target = GMM(dim=d, loc=loc, scale=scale, mixture_weights=torch.ones(1))
+    prior = IsotropicGauss(dim=d, scale=3.0)
+    solver = LangevinSolver(target, prior, eval_timesteps=partial(get_timesteps, 0.0, 8.0, steps=1600),
+                            integrator=EulerIntegrator(dt=None, steps=1600, seed=9), diff_coeff=2.0 ** 0.5, eval_batch_size=16384,
+                            eval_expectation_burn=1200, device=gpu)
+    res = solver.run()
+    assert res.xs.shape == (1601, 16384, d) and res.samples.shape == (16384, d) and bool(torch.isfinite(res.xs).all())
+    mean, std = res.samples.mean(0).cpu(), res.samples.std(0).cpu()
+    print("langevin solver: mean err", float((mean - loc[0]).abs().max()), "std err", float((std / scale[0] - 1).abs().max()))
+    assert float((mean - loc[0]).abs().max()) < 0.06 and float((std / scale[0] - 1).abs().max()) < 0.05
+    want_sq = float((loc ** 2 + scale ** 2).sum())
+    assert abs(float(res.expectation_preds["square"]) - want_sq) < 0.03 * want_sq
+    assert "eval/sample_time" in res.metrics

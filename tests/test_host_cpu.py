@@ -166,3 +166,39 @@ def test_fit_gmm_gives_a_diagonal_reference():
     w, m, v = fit_gmm(2, data)
     assert w.shape == (2,) and m.shape == (2, 3) and v.shape == (2, 3)
     assert abs(float(w.sum()) - 1.0) < 1e-5 and float(m.abs().mean()) > 2.0
+
+
+def test_interpolate_states_equals_the_reference_bookkeeping():
+    """eq.integrator.interpolate_states (all steps at once) == the step-by-step emission of eq/integrator.py:110-128,
+    on grids where ts hits grid points, falls between them, and several ts fall inside one step."""
+    from oracle import sde_oracle as orc
+    from sde_sampler_lrds_amd.eq.integrator import interpolate, interpolate_states
+    g = torch.Generator().manual_seed(3)
+    for n_grid, n_out in ((12, 5), (9, 30), (17, 17)):
+        grid = torch.cat([torch.zeros(1), torch.sort(torch.rand(n_grid - 1, generator=g)).values, torch.ones(1)])
+        ts = torch.linspace(0.0, 1.0, n_out)
+        x0 = torch.randn(6, 3, generator=g)
+        incs = torch.randn(n_grid, 6, 3, generator=g)
+        drift, diff = (lambda s, x: -0.7 * x), (lambda s: torch.tensor(0.9))
+        want = orc.euler_integrate(drift, diff, ts, x0, grid, lambda k, s, t, x: incs[k] * torch.sqrt(t - s))
+        states = [x0]
+        for k in range(n_grid):
+            s_, t_ = grid[k], grid[k + 1]
+            states.append(states[-1] + drift(s_, states[-1]) * (t_ - s_) + diff(s_) * (incs[k] * torch.sqrt(t_ - s_)))
+        got = interpolate_states(ts, grid, torch.stack(states))
+        assert torch.equal(got, want)
+        # on the grid itself the states come back exactly
+        assert torch.equal(interpolate_states(grid, grid, torch.stack(states)), torch.stack(states))
+    # the single-step helper keeps the reference's signature and result
+    xs, xt = torch.zeros(2, 2), torch.ones(2, 2)
+    out = interpolate(torch.tensor([0.25, 0.5, 0.9]), torch.tensor(0.0), torch.tensor(0.5), xs, xt)
+    assert out.shape == (2, 2, 2) and torch.allclose(out[0], torch.full((2, 2), 0.5))
+
+
+def test_euler_states_refuses_cpu_and_unknown_sdes():
+    from sde_sampler_lrds_amd import engine as E
+    from sde_sampler_lrds_amd.eq.integrator import EulerIntegrator
+    from sde_sampler_lrds_amd.eq.sdes import VP
+    with pytest.raises(RuntimeError, match="MI355X"):
+        EulerIntegrator().integrate(VP(0.1, 10.0, 1.0), torch.linspace(0, 1, 5), torch.zeros(4, 3), timesteps=torch.linspace(0, 1, 5))
+    assert E.L.CTRL_NONE == 3

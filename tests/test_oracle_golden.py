@@ -37,6 +37,19 @@ def test_compute_eubo_matches_reference(name):
     assert float((rnd - c["rnd"]).abs().max()) < TOL_SIM * max(1.0, float(c["rnd"].abs().max()))
 
 
+@pytest.mark.parametrize("name", gc.EULER_CASES)
+def test_euler_integrator_matches_reference(name):
+    """eq/integrator.py:93-129 restated (oracle.euler_integrate) vs the reference's EulerIntegrator on Langevin,
+    uncontrolled and controlled SDEs: the interpolated states on the coarse grid, and the last state of the full grid."""
+    c = gc.load(name)
+    out = gc.run_oracle_euler(c)
+    assert out.shape == c["out_xs"].shape
+    assert gc.rel_err(out, c["out_xs"]) < TOL_SIM
+    full = gc.run_oracle_euler(c, ts=c["timesteps"])
+    assert gc.rel_err(full[-1], c["out_last"]) < TOL_SIM
+    assert torch.equal(full[0], c["x0"])
+
+
 def test_unit_vectors():
     c = gc.load("unit_vectors")
     x = c["gmm_x"]
