@@ -54,6 +54,13 @@ def mala_step(y, target_log_prob_y, target_grad_y, target_log_prob_and_grad, ste
 
 
 @torch.no_grad()
+def ula_step(y, target_log_prob_y, target_grad_y, target_log_prob_and_grad, step_size):
+    """additions/mcmc.py:189-221: the unadjusted Langevin move (always accepted)."""
+    y_prop = sample_multivariate_normal_diag(y.shape[0], y + step_size * target_grad_y, 2.0 * step_size)
+    return (y_prop, *target_log_prob_and_grad(y_prop))
+
+
+@torch.no_grad()
 def rwmh_step(y, target_log_prob_y, target_log_prob, step_size):
     """additions/mcmc.py:256-293."""
     y_prop = y + step_size * torch.randn_like(y)

@@ -822,6 +822,29 @@ def case_euler(name, kind, d, B, N, seed, n_out=7):
     print(f"   |x_T| max {float(full[-1].abs().max()):.3f}")
 
 
+def case_sampler(name, kind, seed, B=32, d=3, n_levels=5, n_warm=4, n_steps=3, **kw):
+    """additions/ebm_mle.py: smc_sampler (:11-195) and re_sampler (:269-400) run on CPU with torch's global generator
+    seeded; the annealing path is the closed form of tests/golden_cases.py (an INPUT of the fixture).  The product's
+    samplers consume random numbers in the same order, so the outputs are compared entry by entry."""
+    from sde_sampler.additions import ebm_mle as r_ebm
+    from tests import golden_cases as gc
+    meta = dict(kind="sampler", sampler=kind, seed=seed, B=B, d=d, n_levels=n_levels, n_warm=n_warm, n_steps=n_steps, step=0.05, kw=kw)
+    x_init, times, steps = gc.sampler_inputs(meta)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        if kind == "smc":
+            samples, steps_out, diags = r_ebm.smc_sampler(x_init, times, gc.tempered_log_prob_and_grads, n_warm, n_steps, steps.clone(),
+                                                          verbose=False, **kw)
+        else:
+            samples, steps_out, diags = r_ebm.re_sampler(x_init, times, gc.tempered_log_prob_and_grads, kw.pop("swap_frequency", 3), n_warm,
+                                                         n_steps, steps.clone(), verbose=False, **kw)
+            meta["kw"] = dict(kw, swap_frequency=3)
+    arrays = dict(samples=samples, steps_out=steps_out.reshape(n_levels, B, 1))
+    for k, v in diags.items():
+        arrays["diag_" + k] = torch.as_tensor(v).float()
+    save(name, meta, arrays)
+
+
 CASES = {
     "unit_vectors": unit_vectors,
     # config 2 family (ManyModes d=128, RDS gmm-ref, VP, EI)
@@ -866,6 +889,11 @@ CASES = {
     "euler_langevin_rings_d2": lambda n: case_euler(n, "langevin_rings", d=2, B=96, N=48, seed=83),
     "euler_ou_vp_d40": lambda n: case_euler(n, "ou_vp", d=40, B=32, N=24, seed=84),
     "euler_controlled_vp_d16": lambda n: case_euler(n, "controlled_vp", d=16, B=48, N=32, seed=85),
+    # SMC / replica-exchange samplers (additions/ebm_mle.py)
+    "smc_tempered_d3": lambda n: case_sampler(n, "smc", seed=91, reweight_threshold=0.7),
+    "smc_annealed_langevin_d3": lambda n: case_sampler(n, "smc", seed=92, reweight_threshold=0.0, use_ula=True),
+    "re_tempered_d3": lambda n: case_sampler(n, "re", seed=93, n_steps=9, swap_frequency=3),
+    "re_ula_d3": lambda n: case_sampler(n, "re", seed=94, n_steps=7, swap_frequency=3, use_ula=True),
     # DIS variants
     "dis_ei_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=51, kind="ei"),
     "dis_orig_lerp_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=64, seed=52, kind="orig"),

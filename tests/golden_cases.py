@@ -217,3 +217,28 @@ def run_oracle_euler(c: Case, ts=None, increment=None):
         drift, diff = orc.controlled_sde_drift(sde, ctrl), sde.diff
     with torch.no_grad():
         return orc.euler_integrate(drift, diff, c["ts"] if ts is None else ts, c["x0"], c["timesteps"], increment or euler_increment(c))
+
+
+SAMPLER_CASES = ["smc_tempered_d3", "smc_annealed_langevin_d3", "re_tempered_d3", "re_ula_d3"]  # additions/ebm_mle.py samplers
+
+
+def tempered_log_prob_and_grads(t, x):
+    """Closed-form annealing path used as the INPUT of the sampler fixtures: N(0, 9 I)^(1-t) * (two Gaussian modes)^t,
+    one t per row.  Returns (log-density [B], gradient [B,d])."""
+    m, v = 2.0, 0.3
+    lp0, g0 = -0.5 * (x ** 2).sum(-1) / 9.0, -x / 9.0
+    la, lb = -0.5 * ((x - m) ** 2).sum(-1) / v, -0.5 * ((x + m) ** 2).sum(-1) / v
+    lp1 = torch.logsumexp(torch.stack([la, lb]), dim=0)
+    ra = torch.exp(la - lp1).unsqueeze(-1)
+    g1 = -(ra * (x - m) + (1.0 - ra) * (x + m)) / v
+    w = t.reshape(-1, 1)
+    return ((1.0 - w[:, 0]) * lp0 + w[:, 0] * lp1), (1.0 - w) * g0 + w * g1
+
+
+def sampler_inputs(m):
+    """x_init, times [n_levels,B,1], step sizes [n_levels,B,1] of a sampler fixture (regenerated from its meta)."""
+    g = torch.Generator().manual_seed(m["seed"])
+    x_init = 3.0 * torch.randn(m["B"], m["d"], generator=g)
+    times = torch.linspace(1.0, 0.0, m["n_levels"]).view(-1, 1, 1).repeat(1, m["B"], 1)  # visited last -> first: prior first
+    steps = torch.full((m["n_levels"], m["B"], 1), m["step"])
+    return x_init, times, steps

@@ -202,3 +202,41 @@ def test_euler_states_refuses_cpu_and_unknown_sdes():
     with pytest.raises(RuntimeError, match="MI355X"):
         EulerIntegrator().integrate(VP(0.1, 10.0, 1.0), torch.linspace(0, 1, 5), torch.zeros(4, 3), timesteps=torch.linspace(0, 1, 5))
     assert E.L.CTRL_NONE == 3
+
+
+@pytest.mark.parametrize("name", __import__("tests.golden_cases", fromlist=["x"]).SAMPLER_CASES)
+def test_annealed_samplers_match_reference_fixture(name):
+    """additions/ebm_mle.py smc_sampler / re_sampler (and the MALA / ULA moves under them) against the reference's own
+    output: same inputs, same seed of torch's global generator, same random-number consumption order -> same chains."""
+    from sde_sampler_lrds_amd.additions import ebm_mle
+    from tests import golden_cases as gc
+    c = gc.load(name)
+    m = c.meta
+    x_init, times, steps = gc.sampler_inputs(m)
+    kw = dict(m["kw"])
+    torch.manual_seed(m["seed"])
+    if m["sampler"] == "smc":
+        samples, steps_out, diags = ebm_mle.smc_sampler(x_init, times, gc.tempered_log_prob_and_grads, m["n_warm"], m["n_steps"], steps.clone(), **kw)
+    else:
+        samples, steps_out, diags = ebm_mle.re_sampler(x_init, times, gc.tempered_log_prob_and_grads, kw.pop("swap_frequency"), m["n_warm"],
+                                                       m["n_steps"], steps.clone(), **kw)
+    assert samples.shape == c["samples"].shape
+    assert float((samples - c["samples"]).abs().max()) < 1e-5
+    assert float((steps_out.reshape(m["n_levels"], m["B"], 1) - c["steps_out"]).abs().max()) < 1e-7
+    for k, v in diags.items():
+        assert float((torch.as_tensor(v).float() - c["diag_" + k]).abs().max()) < 1e-5, k
+    if name == "smc_tempered_d3":
+        assert float(c["diag_ess"].min()) < 0.7  # the fixture did go through the resampling branch
+
+
+def test_sampler_refusals_and_pairings():
+    from sde_sampler_lrds_amd.additions import ebm_mle
+    a, b = ebm_mle.make_re_pairings(6)
+    assert a.tolist() == [[0, 1], [2, 3], [4, 5]] and b.tolist() == [[1, 2], [3, 4]]
+    x, t, st = torch.zeros(4, 2), torch.zeros(3, 4, 1), torch.ones(3, 4, 1)
+    with pytest.raises(NotImplementedError):
+        ebm_mle.smc_sampler(x, t, None, 1, 1, st, precond_matrix_per_noise=torch.eye(2), precond_matrix_chol_per_noise=torch.eye(2))
+    with pytest.raises(NotImplementedError):
+        ebm_mle.smc_sampler(x, t, None, 1, 1, st, use_pdds_weights=True, sde=object())
+    with pytest.raises(ValueError):
+        ebm_mle.smc_sampler(torch.zeros(3, 4, 2), t, None, 1, 1, st, per_noise_init=True, reweight_threshold=1.0)

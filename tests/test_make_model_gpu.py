@@ -86,3 +86,41 @@ def test_learned_reference_pipeline(gpu):
     res = TrainableWrapper(model, verbose=False).run()
     assert math.isfinite(res.metrics["eval/elbo"]) and math.isfinite(res.metrics["eval/eubo"])
     assert res.metrics["eval/norm_effective_sample_size"] > 0.2  # a good reference makes the sampler nearly exact already
+
+
+@pytest.mark.gpu
+def test_smc_and_replica_exchange_on_hip_densities(gpu):
+    """additions/ebm_mle.py samplers driven by the HIP distribution kernels (hip_tempered_log_prob_and_grads): the tempered
+    density/gradient equal the torch formulas, SMC moves a wide Gaussian onto a 3-mode mixture with the right mode weights, and
+    replica exchange keeps the target level on it."""
+    from sde_sampler_lrds_amd.additions import ebm_mle
+    from sde_sampler_lrds_amd.distr.gauss import GMM, IsotropicGauss
+    torch.manual_seed(0)
+    d, B, n_levels = 4, 4096, 12
+    loc = torch.tensor([[3.0, 0, 0, 0], [-3.0, 0, 0, 0], [0, 3.0, 0, 0]])
+    wts = torch.tensor([0.5, 0.3, 0.2])
+    target = GMM(dim=d, loc=loc, scale=0.6 * torch.ones(3, d), mixture_weights=wts.clone()).to(gpu)
+    prior = IsotropicGauss(dim=d, scale=3.0).to(gpu)
+    f = ebm_mle.hip_tempered_log_prob_and_grads(target, prior)
+    x = 2.0 * torch.randn(257, d, device=gpu)
+    t = torch.rand(257, 1, device=gpu)
+    lp, g = f(t, x)
+    lp_t = ((1 - t) * prior.unnorm_log_prob(x) + t * target.unnorm_log_prob(x)).flatten()
+    g_t = (1 - t) * prior.score(x) + t * target.score(x)
+    assert float(((lp - lp_t).abs() / lp_t.abs().clamp(min=1)).max()) < 1e-5 and float((g - g_t).abs().max()) < 1e-4
+
+    times = torch.linspace(1.0, 0.0, n_levels, device=gpu).view(-1, 1, 1).repeat(1, B, 1)
+    steps = torch.full((n_levels, B, 1), 0.05, device=gpu)
+    samples, steps, diags = ebm_mle.smc_sampler(prior.sample((B,)), times, f, 8, 4, steps, reweight_threshold=1.0)  # resample at every level: the returned particles are then unweighted
+    final = samples[0, -1]
+    mode = torch.cdist(final, loc.to(gpu)).argmin(dim=1)
+    freq = torch.bincount(mode, minlength=3).float().cpu() / B
+    print("smc mode frequencies", freq.tolist(), "ess", [round(float(v), 2) for v in diags["ess"]], "acc", float(diags["local_acc"].mean()))
+    assert float((freq - wts).abs().max()) < 0.06
+    assert 0.4 < float(diags["local_acc"].mean()) <= 1.0 and float(diags["ess"].min()) > 0.0
+
+    steps = torch.full((n_levels, 512, 1), 0.05, device=gpu)
+    rs, _, rd = ebm_mle.re_sampler(final[:512].clone(), times[:, :512], f, 4, 20, 8, steps)
+    assert rs.shape == (n_levels, 8, 512, d) and bool(torch.isfinite(rs).all()) and 0.0 <= float(rd["swap_acc"]) <= 1.0
+    near = torch.cdist(rs[0, -1], loc.to(gpu)).min(dim=1).values
+    assert float(near.mean()) < 2.0  # the t = 1 level stays on the modes
