@@ -161,7 +161,7 @@ class BaseOCLoss:
             x_n, _, xs = simulate(x, z)
             const = terminal(x_n)
             if rnd0 is not None:
-                const = const + rnd0(x).view((-1, 1))
+                const = const + self._logp(rnd0, x)
         coef = self._coef(ts, x.device, **(coef_kw or {}))
         c_run = (2.0 * coef[:, 4]) if lin else coef[:, 4]  # omega | beta^2 sigma^2 (LIN forms)  or dt (EM)
         u = ctrl_batched(self.generative_ctrl, coef[:, 0], xs[:-1])  # coef[:, 0]: the net's time of step k
@@ -171,6 +171,20 @@ class BaseOCLoss:
         return self.compute_loss(rnd.view(B, 1) + const, samples=x_n)
 
     # ---- engine plumbing ---------------------------------------------------------------------
+    @staticmethod
+    def _logp(fn, x):
+        """Gradient-free log-density ``fn(x)`` as [B,1]: one ``sdeng_dist_eval`` launch when ``fn`` is a method of a
+        distribution the engine knows (a torch.distributions evaluation costs ~1 ms of host time per call, mostly argument
+        validation with device read-backs); the callable itself otherwise."""
+        res = E.resolve_logp(fn)
+        if res is not None:
+            try:
+                logp, _ = E.dist_eval(res[0], x, want_logp=True, want_score=False)
+                return logp if not res[1] else logp.clip(min=-res[1], max=res[1])  # clipped_target_unnorm_log_prob, solver/oc.py:80-87
+            except E.UnsupportedByEngine:
+                pass
+        return fn(x).view((-1, 1))
+
     def _ctrl(self, use_ema):
         return self.generative_ctrl_ema if use_ema else self.generative_ctrl
 
@@ -301,7 +315,7 @@ class EMReferenceSDELoss(BaseOCLoss):
         def sim(xx, z):
             return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
                                  change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
-        return self._lv_loss(ts, x, sim, lambda xn: reference_log_prob(xn).view((-1, 1)) - terminal_unnorm_log_prob(xn),
+        return self._lv_loss(ts, x, sim, lambda xn: self._logp(reference_log_prob, xn) - self._logp(terminal_unnorm_log_prob, xn),
                              lin=self.kind != "em", coef_kw=dict(with_ref=E.resolve_reference(self.reference_ctrl)[0] != "none"))
 
     def compute_eubo(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, use_ema=False, *, noise=None):
@@ -486,7 +500,7 @@ class DiscreteTimeReversalLossEI(_InitialLogProbLoss):
                                  change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
         if self.method in ("kl", "kl_ito"):
             raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
-        return self._lv_loss(ts, x, sim, lambda xn: -terminal_unnorm_log_prob(xn), lin=True, rnd0=initial_log_prob)
+        return self._lv_loss(ts, x, sim, lambda xn: -self._logp(terminal_unnorm_log_prob, xn), lin=True, rnd0=initial_log_prob)
 
     def compute_eubo(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, use_ema=False, *, noise=None):
         """losses/oc.py:980-1036: noising trajectories from target samples (no reference; cost 0.5|u|^2 omega, Ito term,
@@ -533,7 +547,7 @@ class TimeReversalLoss(_InitialLogProbLoss):
         def sim(xx, z):
             return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=None, train=True,
                                  compute_ito_int=True, change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
-        return self._lv_loss(ts, x, sim, lambda xn: -terminal_unnorm_log_prob(xn), lin=False, rnd0=initial_log_prob,
+        return self._lv_loss(ts, x, sim, lambda xn: -self._logp(terminal_unnorm_log_prob, xn), lin=False, rnd0=initial_log_prob,
                              coef_kw=dict(train=True, dim=x.shape[-1], lerp=lerp))
 
 
@@ -558,7 +572,7 @@ class ExponentialIntegratorSDELoss(BaseOCLoss):
         def sim(xx, z):
             return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
                                  compute_ito_int=True, change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
-        return self._lv_loss(ts, x, sim, lambda xn: reference_log_prob(xn).view((-1, 1)) - terminal_unnorm_log_prob(xn), lin=True,
+        return self._lv_loss(ts, x, sim, lambda xn: self._logp(reference_log_prob, xn) - self._logp(terminal_unnorm_log_prob, xn), lin=True,
                              coef_kw=dict(alpha=self.alpha, sigma=self.sigma))
 
     def eval(self, ts, x, terminal_unnorm_log_prob, reference_log_prob=None, compute_weights=True, return_traj=True,

@@ -8,6 +8,7 @@ solver/base.py:401-502) is the training direction and is not pr
 """
 from __future__ import annotations
 
+import math
 import time
 from functools import partial
 
@@ -190,10 +191,13 @@ class TrainableDiff:
         loss.backward()
         params = self.trainable_parameters()
         loss_ok = bool(loss.isfinite()) if self.max_loss is None else bool(loss.abs() <= self.max_loss)
+        # one read-back for all parameters (a per-parameter bool() costs a stream synchronisation each): max |grad| is NaN / inf
+        # exactly when some gradient entry is (solver/base.py:425-433 checks every parameter)
+        grads = [p.grad for p in params if p.grad is not None]
+        mg = float(torch.stack([g.abs().max() for g in grads]).max()) if grads else 0.0
         if self.max_grad is None:
-            grad_ok = all(bool(p.grad.isfinite().all()) for p in params if p.grad is not None)
+            grad_ok = math.isfinite(mg)
         else:
-            mg = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
             grad_ok = mg <= self.max_grad
             metrics["train/max_grad"] = mg
         if loss_ok and grad_ok:
