@@ -377,7 +377,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   Layout L;
   if (!make_layout(d, L)) return fail(SDENG_E_INVALID, "bad sizes: B=%d d=%d N=%d (need 1 <= d <= 128)", d->B, d->d, d->N);
   if (d->B == 0) return 0;
-  if (!d->coef || !d->x_in || !d->x_out || !d->rnd_out) return fail(SDENG_E_INVALID, "null coef/x_in/x_out/rnd_out");
+  if ((!d->coef && d->N > 0) || !d->x_in || !d->x_out || !d->rnd_out) return fail(SDENG_E_INVALID, "null coef/x_in/x_out/rnd_out");
   if (!d->workspace || d->workspace_bytes < L.total * sizeof(float))
     return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, L.total * sizeof(float));
   if (static_cast<long long>(d->B) * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "B*d >= 2^31");

@@ -262,3 +262,40 @@ def test_langevin_solver_reaches_the_target(gpu):
     want_sq = float((loc ** 2 + scale ** 2).sum())
     assert abs(float(res.expectation_preds["square"]) - want_sq) < 0.03 * want_sq
     assert "eval/sample_time" in res.metrics
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,B,N", [(1, 2, 1, 3), (128, 4, 17, 1), (33, 3, 16, 2), (5, 4, 100, 0), (64, 2, 15, 7), (17, 9, 33, 5)])
+def test_extreme_shapes_match_oracle(gpu, d, K, B, N):
+    """Smallest and ragged shapes: one particle, one feature, one step, zero steps (x_N = x_0, the log-weight is the terminal
+    cost alone), a batch one short of a tile, d one past a tile boundary; injected noise."""
+    from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, max(N, 1), d=d, K=K, seed=300 + d)
+    if N == 0:
+        ts = ts[:1]
+    z = torch.randn(N, B, d, generator=torch.Generator().manual_seed(d + N))
+    x, rnd, xs = loss.simulate(ts, x0, *args, noise=z.to(gpu) if N else None, return_traj=True, **kw)
+    sde = orc.VP(0.1, 10.0, 1.0, 1.0)
+    tgt = orc.GMMDiag(info["target"].loc.cpu(), info["target"].scale.cpu(), info["target"].mixture_weights.cpu())
+    ctrl = orc.Ctrl({k: v.detach().cpu() for k, v in info["ctrl"].state_dict().items()}, "clipped", clip_model=1e4)
+    means, var, w = info["means"].cpu(), 0.5 * torch.ones(K, d), torch.ones(K)
+    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+    refd = orc.GMMDiag(loc0, v0.sqrt(), w)
+
+    def oracle(xstart):
+        with torch.no_grad():
+            if N == 0:
+                return xstart, refd.logp(xstart).view(-1, 1) - tgt.logp(xstart).view(-1, 1)
+            return orc.simulate_ei_ref(ts.cpu(), xstart, ctrl, sde, tgt.logp, refd.logp,
+                                       lambda t, xx: orc.mog_score(xx, w, *sde.marginal_diag(t, means, var)), orc.InjectedNoise(z))[:2]
+
+    ox, ornd = oracle(x0.cpu())
+    # a grid of one or two steps over [0, 1] takes giant steps (x gain 12, score gain 23): like the fixture tests, allow 10x what a
+    # one-ulp perturbation of x0 does to the oracle itself
+    tol = max(TOL, 10 * gc.rel_err(oracle(x0.cpu() * (1 + 1.2e-7))[0], ox))
+    scale = torch.stack([ornd.flatten().abs(), tgt.logp(ox).flatten().abs(), refd.logp(ox).flatten().abs()]).max(dim=0).values.clamp(min=1.0)
+    ex, er = gc.rel_err(x.cpu(), ox), float(((rnd.cpu().flatten() - ornd.flatten()).abs() / scale).max())
+    print(f"shape d={d} K={K} B={B} N={N}: x_N {ex:.2e}, rnd {er:.2e} (tolerance {tol:.1e})")
+    assert x.shape == (B, d) and rnd.shape == (B, 1) and xs.shape == (N + 1, B, d)
+    assert ex < tol and er < tol
+    assert torch.equal(xs[0], x0) and torch.equal(xs[-1], x)
