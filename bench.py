@@ -114,7 +114,7 @@ def main():
     from sde_sampler_lrds_amd import parallel
     B, N = a.particles, a.sde_steps
     from sde_sampler_lrds_amd.experiments.baseline_configs import build_rds_gmm
-    loss, ts, x0, args, _, parts = build_rds_gmm(device, B, N, K=a.modes, seed=1 + rank)
+    loss, ts, x0, args, _, parts = build_rds_gmm(device, B, N, K=a.modes, seed=1, x_seed=1 + rank)  # one sampler, rank-specific particles
     flops_ps = parts["flops"]
     loss.seed = 1
     loss.particle0 = rank * B  # global particle index -> sharding-independent noise

@@ -43,8 +43,10 @@ def _flops(d):
     return 2 * (2 * 64 * d + 2 * 64 * 64)
 
 
-def build_rds_gmm(device, B, N, d=128, K=4, seed=1):
-    """configs[1]: ManyModes d=128, RDS with a diagonal-GMM reference, VP(0.1, 10), exponential integrator."""
+def build_rds_gmm(device, B, N, d=128, K=4, seed=1, x_seed=None):
+    """configs[1]: ManyModes d=128, RDS with a diagonal-GMM reference, VP(0.1, 10), exponential integrator.
+    ``seed`` fixes the model (drift net, reference means); ``x_seed`` (default: ``seed``) the initial particles, so the ranks
+    of a sharded run build the SAME sampler and draw different particles."""
     torch.manual_seed(seed)
     sde = VP(0.1, 10.0, 1.0, terminal_t=1.0)
     target = ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
@@ -55,7 +57,7 @@ def build_rds_gmm(device, B, N, d=128, K=4, seed=1):
         m.to(device)
     loss = oc.EIReferenceSDELoss(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref)
     ts = get_timesteps(0.0, 1.0, steps=N).to(device)
-    x0 = torch.randn(B, d, generator=torch.Generator().manual_seed(seed)).to(device)
+    x0 = torch.randn(B, d, generator=torch.Generator().manual_seed(seed if x_seed is None else x_seed)).to(device)
     args = (target.unnorm_log_prob, ref.reference_distr.to(device).log_prob)
     info = dict(sde=sde, target=target, ctrl=ctrl, means=means, K=K, d=d, flops=_flops(d),
                 workload=f"ManyModes d={d} K={K}, RDS gmm-ref, VP(0.1,10), EI integrator")
