@@ -3,15 +3,15 @@ Monte Carlo), ``make_re_pairings`` (:198-216), ``re_step`` (:219-266) and ``re_s
 of the local moves of ``additions/mcmc.py``.  They are host compositions: what costs time is ``log_prob_and_grads(t, x)`` at
 every proposal, which ``hip_tempered_log_prob_and_grads`` serves from the HIP distribution kernels (no autograd).
 
-Same arguments, return values, random-number consumption order and diagnostics as the reference for the plain (diagonal)
-moves.  Not provided: the preconditioned moves (``precond_matrix_per_noise``), the PDDS transition (``use_pdds_weights``) and
+Same arguments, return values, random-number consumption order and diagnostics as the reference, including the
+preconditioned moves (``precond_matrix_per_noise``) and the PDDS transition and weights (``use_pdds_weights``).  Not provided:
 the ``MaximumLikelihoodEBM`` trainer around the samplers (an energy-net training loop, outside the simulate path)."""
 from __future__ import annotations
 
 import torch
 
 from .. import engine as E
-from .mcmc import heuristics_step_size, mala_step, ula_step
+from .mcmc import heuristics_step_size, mala_step, precond_mala_step, precond_ula_step, ula_step
 
 
 def hip_tempered_log_prob_and_grads(target, prior):
@@ -25,27 +25,34 @@ def hip_tempered_log_prob_and_grads(target, prior):
     return fn
 
 
-def _refuse(precond_matrix_per_noise, precond_matrix_chol_per_noise, use_pdds_weights=False):
-    if precond_matrix_per_noise is not None or precond_matrix_chol_per_noise is not None:
-        raise NotImplementedError("preconditioned MALA / ULA moves (additions/mcmc.py:137-187, 224-254) are not provided")
-    if use_pdds_weights:
-        raise NotImplementedError("PDDS transitions and weights (additions/ebm_mle.py:88-99) are not provided")
+def _pmul(mat, v):
+    return torch.matmul(mat, v.unsqueeze(-1)).squeeze(-1)
 
 
 class _LocalMove:
-    """One MALA (or ULA) move at a fixed level with the step-size heuristic of additions/mcmc.py:54-72."""
+    """One MALA (or ULA) move at a fixed level, plain or preconditioned, with the step-size heuristic of
+    additions/mcmc.py:54-72.  State: (x, log-density, gradient, preconditioned gradient or None)."""
 
-    def __init__(self, log_prob_and_grad, use_ula, target_acceptance):
-        self.f, self.use_ula, self.target = log_prob_and_grad, use_ula, target_acceptance
+    def __init__(self, log_prob_and_grad, use_ula, target_acceptance, precond=None):
+        self.f, self.use_ula, self.target, self.precond = log_prob_and_grad, use_ula, target_acceptance, precond
 
-    def __call__(self, x, lp, grad, step):
-        if self.use_ula:
+    def pgrad(self, grad):
+        return None if self.precond is None else _pmul(self.precond[0], grad)
+
+    def __call__(self, x, lp, grad, pgrad, step):
+        log_acc = None
+        if self.precond is not None:
+            if self.use_ula:
+                x, lp, grad, pgrad = precond_ula_step(x, lp, grad, pgrad, self.f, step, *self.precond)
+            else:
+                x, lp, grad, pgrad, log_acc = precond_mala_step(x, lp, grad, pgrad, self.f, step, *self.precond)
+        elif self.use_ula:
             x, lp, grad = ula_step(x, lp, grad, self.f, step)
-            return x, lp, grad, step, None
-        x, lp, grad, log_acc = mala_step(x, lp, grad, self.f, step)
-        if self.target > 0.0:
+        else:
+            x, lp, grad, log_acc = mala_step(x, lp, grad, self.f, step)
+        if log_acc is not None and self.target > 0.0:
             step = heuristics_step_size(step, log_acc, target_acceptance=self.target)
-        return x, lp, grad, step, log_acc
+        return x, lp, grad, pgrad, step, log_acc
 
 
 def smc_sampler(x_init, times, log_prob_and_grads, n_warmup_mcmc_steps, n_mcmc_steps, step_sizes_per_noise, per_noise_init=False,
@@ -53,45 +60,65 @@ def smc_sampler(x_init, times, log_prob_and_grads, n_warmup_mcmc_steps, n_mcmc_s
                 precond_matrix_chol_per_noise=None, use_ula=False, verbose=False):
     """additions/ebm_mle.py:11-195.  Levels are visited from the last (``times[-1]``) to the first; with
     ``reweight_threshold > 0`` the particles carry importance weights between levels and are resampled (multinomial) when
-    the normalised ESS drops below the threshold.  Returns (samples [n_levels, n_mcmc_steps, B, *data], updated step sizes, diags)."""
-    _refuse(precond_matrix_per_noise, precond_matrix_chol_per_noise, use_pdds_weights)
+    the normalised ESS drops below the threshold; with ``use_pdds_weights`` they are first moved by the SDE's EI denoising
+    kernel and weighted with the forward / backward transition densities (:88-107).
+    Returns (samples [n_levels, n_mcmc_steps, B, *data], updated step sizes, diags)."""
     if per_noise_init and reweight_threshold > 0.0:
         raise ValueError("Can't use per_noise_init in SMC mode.")
+    if sde is None and use_pdds_weights:
+        raise ValueError("Can't use PDDS weights without the SDE object.")
     n_levels = times.shape[0]
     B = x_init.shape[1] if per_noise_init else x_init.shape[0]
     data_shape = x_init.shape[2:] if per_noise_init else x_init.shape[1:]
     smc = reweight_threshold > 0.0
+    use_precond = precond_matrix_per_noise is not None and precond_matrix_chol_per_noise is not None
     samples = torch.empty((n_levels, n_mcmc_steps, B, *data_shape), device=x_init.device)
     ess_logs = torch.ones((n_levels,))
     mean_accs = torch.empty((n_levels,))
     log_w = torch.zeros((B,), device=x_init.device)
-    x, lp_prev = x_init.clone(), None
+    x, x_prev, lp_prev, grad_prev = x_init.clone(), None, None, None
     for lvl in range(n_levels - 1, -1, -1):
+        first = lvl == n_levels - 1
         x = x_init[lvl].clone() if per_noise_init else x.clone()
-        move = _LocalMove(lambda y, lvl=lvl: log_prob_and_grads(times[lvl], y), use_ula, target_acceptance)
+        precond = (precond_matrix_per_noise[lvl], precond_matrix_chol_per_noise[lvl]) if use_precond else None
+        move = _LocalMove(lambda y, lvl=lvl: log_prob_and_grads(times[lvl], y), use_ula, target_acceptance, precond)
         step = step_sizes_per_noise[lvl]
         lp, grad = move.f(x)
-        if smc and lvl != n_levels - 1:  # incremental weight: this level's density over the previous level's, at the same points
-            log_w += lp - lp_prev
+        pgrad = move.pgrad(grad)
+        if use_pdds_weights and not first:  # reverse-SDE move from the previous level, then the densities at the moved points
+            x, z = sde.ei_integration_step(x_prev, sde.terminal_t - times[lvl + 1], sde.terminal_t - times[lvl], grad_prev)
+            lp_backward = -0.5 * torch.sum(torch.square(z), dim=-1)
+            mean_f, var_f = sde.transition_params(times[lvl], times[lvl + 1])
+            lp_forward = -0.5 * torch.sum(torch.square(mean_f * x - x_prev) / var_f, dim=-1)
+            lp, grad = move.f(x)
+            pgrad = move.pgrad(grad)
+        if smc and not first:
+            if use_pdds_weights:
+                log_w = lp - lp_prev
+                log_w += lp_forward - lp_backward
+            else:  # this level's density over the previous level's, at the same points
+                log_w += lp - lp_prev
             w = torch.nn.functional.softmax(log_w, dim=0)
             ess = (1.0 / torch.sum(torch.square(w))) / B
             ess_logs[lvl] = ess.cpu().clone()
             if ess < reweight_threshold:
                 idx = torch.multinomial(w, B, replacement=True)
                 x, lp, grad = x[idx], lp[idx], grad[idx]
+                if use_precond:
+                    pgrad = pgrad[idx]
                 log_w.zero_()
         for _ in range(n_warmup_mcmc_steps):
-            x, lp, grad, step, _ = move(x, lp, grad, step)
+            x, lp, grad, pgrad, step, _ = move(x, lp, grad, pgrad, step)
         acc_sum = 0.0
         for i in range(n_mcmc_steps):
-            x, lp, grad, step, log_acc = move(x, lp, grad, step)
+            x, lp, grad, pgrad, step, log_acc = move(x, lp, grad, pgrad, step)
             if log_acc is not None:
                 acc_sum = acc_sum + torch.exp(torch.minimum(torch.zeros_like(log_acc), log_acc))
             samples[lvl, i] = x.clone()
         if not use_ula:
             mean_accs[lvl] = (acc_sum / n_mcmc_steps).mean()
         step_sizes_per_noise[lvl] = step.clone()
-        lp_prev = lp.clone()
+        x_prev, grad_prev, lp_prev = x.clone(), grad.clone(), lp.clone()
         if verbose:
             print(f"smc level {lvl}: ess {float(ess_logs[lvl]):.3f}" + ("" if use_ula else f", local acc {float(mean_accs[lvl]):.3f}"))
     diags = {}
@@ -137,7 +164,6 @@ def re_sampler(x_init, times, log_prob_and_grads, swap_frequency, n_warmup_mcmc_
                use_ula=False, verbose=False):
     """additions/ebm_mle.py:269-400: all levels advance together as one flattened batch of n_levels*B chains; every
     ``swap_frequency``-th step is a swap step (even pairs, then odd pairs, alternating) instead of a local move."""
-    _refuse(precond_matrix_per_noise, precond_matrix_chol_per_noise)
     n_levels = times.shape[0]
     B = x_init.shape[1] if per_noise_init else x_init.shape[0]
     data_shape = x_init.shape[2:] if per_noise_init else x_init.shape[1:]
@@ -151,11 +177,16 @@ def re_sampler(x_init, times, log_prob_and_grads, swap_frequency, n_warmup_mcmc_
         lp, g = log_prob_and_grads(t.view((-1, *ones)), y.view((-1, *data_shape)))
         return lp.view(y.shape[:2]), g.view(y.shape)
 
-    move = _LocalMove(lambda y: log_prob_and_grads(t_flat, y), use_ula, target_acceptance)
+    precond = None
+    if precond_matrix_per_noise is not None and precond_matrix_chol_per_noise is not None:  # [n_levels, B, d, d] -> one per chain
+        precond = (precond_matrix_per_noise.view((-1, *precond_matrix_per_noise.shape[2:])),
+                   precond_matrix_chol_per_noise.view((-1, *precond_matrix_chol_per_noise.shape[2:])))
+    move = _LocalMove(lambda y: log_prob_and_grads(t_flat, y), use_ula, target_acceptance, precond)
     x = x_init.clone() if per_noise_init else x_init.unsqueeze(0).repeat((n_levels, 1, *ones))
     x = x.view((-1, *data_shape))
     step = step_sizes_per_noise.view((-1, *ones))
     lp, grad = move.f(x)
+    pgrad = move.pgrad(grad)
     pairs = make_re_pairings(n_levels, x_init.device)
     for it in range(n_warmup_mcmc_steps + n_mcmc_steps):
         if it % swap_frequency == 0:
@@ -163,8 +194,9 @@ def re_sampler(x_init, times, log_prob_and_grads, swap_frequency, n_warmup_mcmc_
             x, lp, grad, mean_swap_acc = re_step(x.view((-1, B, *data_shape)), lp.view((-1, B)), grad.view((-1, B, *data_shape)), batched,
                                                  times, pr[:, 0], pr[:, 1], B, data_shape, ones)
             x, grad, lp = x.view((-1, *data_shape)), grad.view((-1, *data_shape)), lp.flatten()
+            pgrad = move.pgrad(grad)
         else:
-            x, lp, grad, step, log_acc = move(x, lp, grad, step)
+            x, lp, grad, pgrad, step, log_acc = move(x, lp, grad, pgrad, step)
             if log_acc is not None:
                 mean_local_accs = torch.exp(torch.minimum(torch.zeros_like(log_acc), log_acc)).view((-1, B)).mean(dim=-1)
         if it >= n_warmup_mcmc_steps:

@@ -60,6 +60,39 @@ def ula_step(y, target_log_prob_y, target_grad_y, target_log_prob_and_grad, step
     return (y_prop, *target_log_prob_and_grad(y_prop))
 
 
+def _precond_proposal(y, precond_grad_y, step_size, precond_matrix_chol):
+    noise = torch.matmul(precond_matrix_chol, torch.randn((*y.shape, 1), device=y.device)).squeeze(-1)
+    return y + step_size * precond_grad_y + torch.sqrt(2.0 * step_size) * noise
+
+
+@torch.no_grad()
+def precond_mala_step(y, target_log_prob_y, target_grad_y, precond_grad_y, target_log_prob_and_grad, step_size, precond_matrix,
+                      precond_matrix_chol):
+    """additions/mcmc.py:137-187: MALA with proposal covariance 2 h P (P = ``precond_matrix``, its Cholesky factor given); the
+    acceptance ratio in the gradient form of arXiv:2305.14442, Prop. 1."""
+    y_prop = _precond_proposal(y, precond_grad_y, step_size, precond_matrix_chol)
+    lp_prop, grad_prop = target_log_prob_and_grad(y_prop)
+    pgrad_prop = torch.matmul(precond_matrix, grad_prop.unsqueeze(-1)).squeeze(-1)
+    log_acc = lp_prop - target_log_prob_y
+    log_acc = log_acc + 0.5 * torch.sum((y - y_prop - 0.5 * step_size * pgrad_prop) * grad_prop, dim=-1)
+    log_acc = log_acc - 0.5 * torch.sum((y_prop - y - 0.5 * step_size * precond_grad_y) * target_grad_y, dim=-1)
+    mask = torch.log(torch.rand_like(lp_prop)) < log_acc
+    y[mask] = y_prop[mask]
+    target_log_prob_y[mask] = lp_prop[mask]
+    target_grad_y[mask] = grad_prop[mask]
+    precond_grad_y[mask] = pgrad_prop[mask]
+    return y, target_log_prob_y, target_grad_y, precond_grad_y, log_acc
+
+
+@torch.no_grad()
+def precond_ula_step(y, target_log_prob_y, target_grad_y, precond_grad_y, target_log_prob_and_grad, step_size, precond_matrix,
+                     precond_matrix_chol):
+    """additions/mcmc.py:224-253."""
+    y_prop = _precond_proposal(y, precond_grad_y, step_size, precond_matrix_chol)
+    lp_prop, grad_prop = target_log_prob_and_grad(y_prop)
+    return y_prop, lp_prop, grad_prop, torch.matmul(precond_matrix, grad_prop.unsqueeze(-1)).squeeze(-1)
+
+
 @torch.no_grad()
 def rwmh_step(y, target_log_prob_y, target_log_prob, step_size):
     """additions/mcmc.py:256-293."""

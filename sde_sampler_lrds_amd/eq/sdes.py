@@ -195,6 +195,17 @@ class VP(OU):
         return self.scale_diff_coeff ** 2 * (la / lb) * self.lambda_(t_k, t_k_p_1)
 
 
+    def ei_integration_step(self, x, t_k, t_k_p_1, s, z=None):
+        """One EI denoising transition as a host-side torch expression (eq/sdes.py:532-539); the simulate loops do not call
+        this -- their transitions live in the step-loop kernel -- the PDDS move of additions/ebm_mle.smc_sampler does."""
+        lam = self.lambda_(t_k, t_k_p_1)
+        ret = torch.sqrt(1.0 + lam) * x + 2.0 * self.scale_diff_coeff ** 2 * (torch.sqrt(1.0 + lam) - 1.0) * s
+        if z is None:
+            z = torch.randn_like(ret)
+        ret = ret + self.scale_diff_coeff * torch.sqrt(lam) * z
+        return ret, z
+
+
 class CosineVP(VP):
     def __init__(self, c=0.008, scale_diff_coeff=1.0, **kw):
         super().__init__(scale_diff_coeff=scale_diff_coeff, **kw)
@@ -245,3 +256,11 @@ class PinnedBM(OU):
     def omega_ddpm(self, t_k, t_k_p_1):
         T = self.terminal_t
         return self.diff_coeff ** 2 * ((T - t_k) / (T - t_k_p_1)) * (t_k_p_1 - t_k)
+
+    def ei_integration_step(self, x, t_k, t_k_p_1, s, z=None):
+        """eq/sdes.py:658-666 (host-side, see VP.ei_integration_step)."""
+        ret = (t_k_p_1 / t_k) * x + self.diff_coeff ** 2 * (t_k_p_1 - t_k) * s
+        if z is None:
+            z = torch.randn_like(ret)
+        ret = ret + torch.sqrt(self.diff_coeff ** 2 * (t_k_p_1 / t_k) * (t_k_p_1 - t_k)) * z
+        return ret, z

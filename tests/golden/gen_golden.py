@@ -822,23 +822,28 @@ def case_euler(name, kind, d, B, N, seed, n_out=7):
     print(f"   |x_T| max {float(full[-1].abs().max()):.3f}")
 
 
-def case_sampler(name, kind, seed, B=32, d=3, n_levels=5, n_warm=4, n_steps=3, **kw):
+def case_sampler(name, kind, seed, B=32, d=3, n_levels=5, n_warm=4, n_steps=3, precond=False, pdds=False, **kw):
     """additions/ebm_mle.py: smc_sampler (:11-195) and re_sampler (:269-400) run on CPU with torch's global generator
-    seeded; the annealing path is the closed form of tests/golden_cases.py (an INPUT of the fixture).  The product's
-    samplers consume random numbers in the same order, so the outputs are compared entry by entry."""
+    seeded; the annealing path is the closed form of tests/golden_cases.py (an INPUT of the fixture), optionally with
+    preconditioned moves or the PDDS transition (VP(0.1, 10) EI kernel).  The product's samplers consume random numbers in
+    the same order, so the outputs are compared entry by entry."""
     from sde_sampler.additions import ebm_mle as r_ebm
     from tests import golden_cases as gc
-    meta = dict(kind="sampler", sampler=kind, seed=seed, B=B, d=d, n_levels=n_levels, n_warm=n_warm, n_steps=n_steps, step=0.05, kw=kw)
+    meta = dict(kind="sampler", sampler=kind, seed=seed, B=B, d=d, n_levels=n_levels, n_warm=n_warm, n_steps=n_steps, step=0.05,
+                precond=precond, pdds=pdds, kw=dict(kw))
     x_init, times, steps = gc.sampler_inputs(meta)
+    extra = dict(gc.sampler_precond(meta))
+    if pdds:
+        extra.update(use_pdds_weights=True, sde=r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0))
+    fn = gc.sampler_fn(meta)
     torch.manual_seed(seed)
     with torch.no_grad():
         if kind == "smc":
-            samples, steps_out, diags = r_ebm.smc_sampler(x_init, times, gc.tempered_log_prob_and_grads, n_warm, n_steps, steps.clone(),
-                                                          verbose=False, **kw)
+            samples, steps_out, diags = r_ebm.smc_sampler(x_init, times, fn, n_warm, n_steps, steps.clone(), verbose=False, **kw, **extra)
         else:
-            samples, steps_out, diags = r_ebm.re_sampler(x_init, times, gc.tempered_log_prob_and_grads, kw.pop("swap_frequency", 3), n_warm,
-                                                         n_steps, steps.clone(), verbose=False, **kw)
-            meta["kw"] = dict(kw, swap_frequency=3)
+            kw = dict(kw)
+            samples, steps_out, diags = r_ebm.re_sampler(x_init, times, fn, kw.pop("swap_frequency"), n_warm, n_steps, steps.clone(),
+                                                         verbose=False, **kw, **extra)
     arrays = dict(samples=samples, steps_out=steps_out.reshape(n_levels, B, 1))
     for k, v in diags.items():
         arrays["diag_" + k] = torch.as_tensor(v).float()
@@ -894,6 +899,9 @@ CASES = {
     "smc_annealed_langevin_d3": lambda n: case_sampler(n, "smc", seed=92, reweight_threshold=0.0, use_ula=True),
     "re_tempered_d3": lambda n: case_sampler(n, "re", seed=93, n_steps=9, swap_frequency=3),
     "re_ula_d3": lambda n: case_sampler(n, "re", seed=94, n_steps=7, swap_frequency=3, use_ula=True),
+    "smc_precond_d3": lambda n: case_sampler(n, "smc", seed=95, precond=True, reweight_threshold=0.8),
+    "smc_pdds_d3": lambda n: case_sampler(n, "smc", seed=96, pdds=True, reweight_threshold=0.9),
+    "re_precond_d3": lambda n: case_sampler(n, "re", seed=97, n_steps=8, precond=True, swap_frequency=3),
     # DIS variants
     "dis_ei_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=51, kind="ei"),
     "dis_orig_lerp_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=64, seed=52, kind="orig"),

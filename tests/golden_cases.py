@@ -219,7 +219,8 @@ def run_oracle_euler(c: Case, ts=None, increment=None):
         return orc.euler_integrate(drift, diff, c["ts"] if ts is None else ts, c["x0"], c["timesteps"], increment or euler_increment(c))
 
 
-SAMPLER_CASES = ["smc_tempered_d3", "smc_annealed_langevin_d3", "re_tempered_d3", "re_ula_d3"]  # additions/ebm_mle.py samplers
+SAMPLER_CASES = ["smc_tempered_d3", "smc_annealed_langevin_d3", "re_tempered_d3", "re_ula_d3", "smc_precond_d3", "smc_pdds_d3",
+                 "re_precond_d3"]  # additions/ebm_mle.py samplers
 
 
 def tempered_log_prob_and_grads(t, x):
@@ -241,4 +242,25 @@ def sampler_inputs(m):
     x_init = 3.0 * torch.randn(m["B"], m["d"], generator=g)
     times = torch.linspace(1.0, 0.0, m["n_levels"]).view(-1, 1, 1).repeat(1, m["B"], 1)  # visited last -> first: prior first
     steps = torch.full((m["n_levels"], m["B"], 1), m["step"])
+    if m.get("pdds"):  # PDDS: noise levels increase with the level index, strictly inside (0, T)
+        times = torch.linspace(0.05, 0.95, m["n_levels"]).view(-1, 1, 1).repeat(1, m["B"], 1)
     return x_init, times, steps
+
+
+def sampler_fn(m):
+    """The annealing path of a sampler fixture: tempering weight t, or 1 - t when the levels are noise levels (PDDS)."""
+    if m.get("pdds"):
+        return lambda t, x: tempered_log_prob_and_grads(1.0 - t, x)
+    return tempered_log_prob_and_grads
+
+
+def sampler_precond(m):
+    """SPD preconditioners (and their Cholesky factors) of a preconditioned sampler fixture: one per level (SMC, [L,d,d]) or
+    one per level and chain (replica exchange, [L,B,d,d]); None for the plain fixtures."""
+    if not m.get("precond"):
+        return {}
+    g = torch.Generator().manual_seed(m["seed"] + 1000)
+    lead = (m["n_levels"],) if m["sampler"] == "smc" else (m["n_levels"], m["B"])
+    a = torch.randn(*lead, m["d"], m["d"], generator=g)
+    P = 0.3 * a @ a.transpose(-1, -2) + torch.eye(m["d"])
+    return dict(precond_matrix_per_noise=P, precond_matrix_chol_per_noise=torch.linalg.cholesky(P))

@@ -213,13 +213,16 @@ def test_annealed_samplers_match_reference_fixture(name):
     c = gc.load(name)
     m = c.meta
     x_init, times, steps = gc.sampler_inputs(m)
-    kw = dict(m["kw"])
+    kw = dict(m["kw"], **gc.sampler_precond(m))
+    if m.get("pdds"):
+        from sde_sampler_lrds_amd.eq.sdes import VP
+        kw.update(use_pdds_weights=True, sde=VP(0.1, 10.0, 1.0, terminal_t=1.0))
+    fn = gc.sampler_fn(m)
     torch.manual_seed(m["seed"])
     if m["sampler"] == "smc":
-        samples, steps_out, diags = ebm_mle.smc_sampler(x_init, times, gc.tempered_log_prob_and_grads, m["n_warm"], m["n_steps"], steps.clone(), **kw)
+        samples, steps_out, diags = ebm_mle.smc_sampler(x_init, times, fn, m["n_warm"], m["n_steps"], steps.clone(), **kw)
     else:
-        samples, steps_out, diags = ebm_mle.re_sampler(x_init, times, gc.tempered_log_prob_and_grads, kw.pop("swap_frequency"), m["n_warm"],
-                                                       m["n_steps"], steps.clone(), **kw)
+        samples, steps_out, diags = ebm_mle.re_sampler(x_init, times, fn, kw.pop("swap_frequency"), m["n_warm"], m["n_steps"], steps.clone(), **kw)
     assert samples.shape == c["samples"].shape
     assert float((samples - c["samples"]).abs().max()) < 1e-5
     assert float((steps_out.reshape(m["n_levels"], m["B"], 1) - c["steps_out"]).abs().max()) < 1e-7
@@ -234,9 +237,7 @@ def test_sampler_refusals_and_pairings():
     a, b = ebm_mle.make_re_pairings(6)
     assert a.tolist() == [[0, 1], [2, 3], [4, 5]] and b.tolist() == [[1, 2], [3, 4]]
     x, t, st = torch.zeros(4, 2), torch.zeros(3, 4, 1), torch.ones(3, 4, 1)
-    with pytest.raises(NotImplementedError):
-        ebm_mle.smc_sampler(x, t, None, 1, 1, st, precond_matrix_per_noise=torch.eye(2), precond_matrix_chol_per_noise=torch.eye(2))
-    with pytest.raises(NotImplementedError):
-        ebm_mle.smc_sampler(x, t, None, 1, 1, st, use_pdds_weights=True, sde=object())
+    with pytest.raises(ValueError):
+        ebm_mle.smc_sampler(x, t, None, 1, 1, st, use_pdds_weights=True, sde=None)
     with pytest.raises(ValueError):
         ebm_mle.smc_sampler(torch.zeros(3, 4, 2), t, None, 1, 1, st, per_noise_init=True, reweight_threshold=1.0)
