@@ -12,7 +12,6 @@ import argparse
 import hashlib
 import os
 import subprocess
-import sys
 from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))

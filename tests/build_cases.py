@@ -2,11 +2,10 @@
 drive the engine exactly the way a user of the reference's API would."""
 from __future__ import annotations
 
-import math
 
 import torch
 
-from sde_sampler_lrds_amd.distr.delta import Delta
+
 from sde_sampler_lrds_amd.distr.gauss import GMM, Gauss, GaussFull, IsotropicGauss
 from sde_sampler_lrds_amd.distr.logistic_regression import LogisticRegression
 from sde_sampler_lrds_amd.distr.phi_four import PhiFour

@@ -136,7 +136,6 @@ def test_partial_tiles_and_sharding_independence(gpu):
 
 @pytest.mark.gpu
 def test_philox_kernel_vs_oracle(gpu):
-    import ctypes as C
     from sde_sampler_lrds_amd import _lib as L
     out = torch.empty(300, 37, device=gpu)
     L.check(L.lib().sdeng_philox_normal(12345678901234, 7, 1000, 300, 37, 0, out.data_ptr(), None))

@@ -2,7 +2,6 @@
 the d = 128 instantiation spills."""
 import os
 import sys
-import time
 
 import torch
 
