@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDENG_ABI_VERSION 1
+#define SDENG_ABI_VERSION 2
 
 /* error codes */
 #define SDENG_OK 0
@@ -155,12 +155,19 @@ typedef struct sdeng_net {
 #define SDENG_REF_GAUSS_DIAG 1 /* marginal_score, diagonal var_init            eq/sdes.py:265-279 */
 #define SDENG_REF_GMM_DIAG 2   /* marginal_gmm_score, diagonal variances_init  eq/sdes.py:329-345 */
 
+/* marginal_gmm_score with full covariance matrices, score_mog_full (distr/gauss.py:110-121, eq/sdes.py:329-345), in the
+ * eigen form the reference itself accepts (eq/sdes.py:228-238: variances_init = (D, P), covariance_c = P_c diag(D_c) P_c^T):
+ * vars_init holds the eigenvalues D [k,d], eigvecs the eigenvectors P [k,d,d] row-major (P[c][i][j] = i-th coordinate of
+ * the j-th eigenvector).  A caller holding covariance matrices passes their symmetric eigendecomposition. */
+#define SDENG_REF_GMM_FULL 3
+
 typedef struct sdeng_ref {
   int32_t kind;
   int32_t k;               /* GMM components (1 for GAUSS_DIAG)                      */
   const float* means_init; /* [k,d]                                                   */
-  const float* vars_init;  /* [k,d]                                                   */
+  const float* vars_init;  /* [k,d]  (GMM_FULL: eigenvalues of the covariances)      */
   const float* weights;    /* [k] unnormalised (normalised like distr/gauss.py:100)   */
+  const float* eigvecs;    /* [k,d,d] GMM_FULL only, else NULL                        */
 } sdeng_ref;
 
 /* ---- noise ---------------------------------------------------------------------------------

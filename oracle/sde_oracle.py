@@ -106,6 +106,21 @@ class OUBase:
             var = var + self.s(t) ** 2 * var0
         return loc, var
 
+    def marginal_full(self, t, loc0, cov0):
+        """eq/sdes.py:208-248 with full covariance matrices [K,d,d]: (s m, s^2 sigma^2 I + s^2 C)."""
+        loc = self.s(t) * loc0
+        var = self.s(t) ** 2 * self.sigma_sq(t)
+        return loc, var * torch.eye(cov0.shape[-1]).unsqueeze(0) + self.s(t) ** 2 * cov0
+
+    def marginal_eigen(self, t, loc0, D, P):
+        """eq/sdes.py:228-238: covariances given as (D, P), C = P diag(D) P^T -> (s m, precision, log det) of the noised marginal."""
+        diag = D + self.sigma_sq(t)
+        prec = torch.einsum("...ik,...k,...jk->...ij", P, 1.0 / diag, P)
+        prec = prec / self.s(t) ** 2
+        log_det = torch.sum(torch.log(diag), dim=-1)
+        log_det = log_det + 2.0 * diag.shape[-1] * torch.log(self.s(t))
+        return self.s(t) * loc0, prec, log_det
+
     def log_snr(self, t):  # :347-351  (t may be a python float: kept as is, like upstream)
         a = self.s(t)
         v = torch.square(a) * self.sigma_sq(t)
@@ -284,6 +299,60 @@ def mog_score(x, w, mean, var):
     w = w / w.sum()
     p = torch.softmax(torch.log(w.unsqueeze(0)) + mog_component_logp(x, mean, var), dim=-1)
     return -torch.sum(p.unsqueeze(-1) * (x.unsqueeze(1) - mean.unsqueeze(0)) / var.unsqueeze(0), dim=1)
+
+
+def mog_full_logp_and_ptd(x, mean, cov):
+    """distr/gauss.py:75-94 log_prob_gaussian_full with covariance matrices: (log N(x; m_c, C_c) [B,K], C_c^-1 (x - m_c) [B,K,d])."""
+    diff = x.unsqueeze(1) - mean.unsqueeze(0)
+    ptd = torch.linalg.solve(cov.unsqueeze(0), diff.unsqueeze(-1)).squeeze(-1)
+    lp = -0.5 * torch.sum(diff * ptd, dim=-1)
+    lp = lp - 0.5 * mean.shape[-1] * math.log(2.0 * math.pi)
+    lp = lp - 0.5 * torch.logdet(cov).unsqueeze(0)
+    return lp, ptd
+
+
+def mog_score_full(x, w, mean, cov):
+    """distr/gauss.py:110-121 score_mog_full (covariance form)."""
+    w = w / w.sum()
+    lp, ptd = mog_full_logp_and_ptd(x, mean, cov)
+    p = torch.softmax(torch.log(w.unsqueeze(0)) + lp, dim=-1)
+    return -torch.sum(p.unsqueeze(-1) * ptd, dim=1)
+
+
+def mog_score_full_prec(x, w, mean, prec, log_det):
+    """distr/gauss.py:110-121 score_mog_full in the precision form (precisions and log-determinants given, :81-90)."""
+    w = w / w.sum()
+    diff = x.unsqueeze(1) - mean.unsqueeze(0)
+    ptd = torch.matmul(prec.unsqueeze(0), diff.unsqueeze(-1)).squeeze(-1)
+    lp = -0.5 * torch.sum(diff * ptd, dim=-1)
+    lp = lp - 0.5 * mean.shape[-1] * math.log(2.0 * math.pi)
+    lp = lp - 0.5 * log_det.unsqueeze(0)
+    p = torch.softmax(torch.log(w.unsqueeze(0)) + lp, dim=-1)
+    return -torch.sum(p.unsqueeze(-1) * ptd, dim=1)
+
+
+class GMMFullPrec:
+    """distr/gauss.py GMMFull built from precisions and covariance log-determinants (eq/sdes.py:316-318)."""
+
+    def __init__(self, loc, prec, log_det, weights):
+        self.loc, self.prec, self.log_det, self.w = loc, prec, log_det, weights / weights.sum()
+
+    def logp(self, x):
+        diff = x.unsqueeze(1) - self.loc.unsqueeze(0)
+        ptd = torch.matmul(self.prec.unsqueeze(0), diff.unsqueeze(-1)).squeeze(-1)
+        lp = -0.5 * torch.sum(diff * ptd, dim=-1) - 0.5 * self.loc.shape[-1] * math.log(2.0 * math.pi) - 0.5 * self.log_det.unsqueeze(0)
+        return torch.logsumexp(torch.log(self.w).unsqueeze(0) + lp, dim=-1, keepdim=True)
+
+
+class GMMFullCov:
+    """distr/gauss.py GMMFull (covariance form): log-density of a full-covariance mixture."""
+
+    def __init__(self, loc, cov, weights):
+        self.loc, self.cov, self.w = loc, cov, weights / weights.sum()
+
+    def logp(self, x):
+        lp, _ = mog_full_logp_and_ptd(x, self.loc, self.cov)
+        return torch.logsumexp(torch.log(self.w).unsqueeze(0) + lp, dim=-1, keepdim=True)
 
 
 def gauss_score(x, mean, var):

@@ -8,14 +8,14 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NCOEF = 16
 
 FORM_LIN, FORM_EM, FORM_CMCD, FORM_EUBO, FORM_CMCD_EUBO = 0, 1, 2, 3, 4
 FLAG_ITO, FLAG_INIT_LOGP, FLAG_TERM_REF, FLAG_TERM_TARGET = 1, 2, 4, 8
 DIST_NONE, DIST_GMM_DIAG, DIST_GAUSS_DIAG, DIST_ISO_GAUSS, DIST_PHI4, DIST_LOGREG, DIST_GAUSS_FULL, DIST_RINGS = range(8)
 CTRL_CLIPPED, CTRL_SCORE, CTRL_LERP, CTRL_NONE = 0, 1, 2, 3
-REF_NONE, REF_GAUSS_DIAG, REF_GMM_DIAG = 0, 1, 2
+REF_NONE, REF_GAUSS_DIAG, REF_GMM_DIAG, REF_GMM_FULL = 0, 1, 2, 3
 
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_HIP = -1, -2, -3, -4
 
@@ -40,7 +40,7 @@ class Net(C.Structure):
 
 
 class Ref(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("means_init", _fp), ("vars_init", _fp), ("weights", _fp)]
+    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("means_init", _fp), ("vars_init", _fp), ("weights", _fp), ("eigvecs", _fp)]
 
 
 class Desc(C.Structure):

@@ -51,6 +51,10 @@ def sources():
         path = os.path.join(GEN, f"sim_{dt}_0_3.hip")
         _write_if_changed(path, '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, 0, 3, {fm})\n" for fm in FORMS))
         srcs.append(path)
+    for dt in DTS:  # full-covariance mixture reference (REF = 4): ClippedCtrl; forward forms and the noising loop (3 = EUBO)
+        path = os.path.join(GEN, f"sim_{dt}_4_0.hip")
+        _write_if_changed(path, '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, 4, 0, {fm})\n" for fm in FORMS + (3,)))
+        srcs.append(path)
     for dt in DTS:
         for rf in REFS:
             for sc in SCS:

@@ -142,6 +142,64 @@ __global__ void __launch_bounds__(128) k_ref_tables(RefTabArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Full-covariance mixture reference per step (eq/sdes.py:228-238 in the reference's own eigen form: covariance_c =
+// U_c diag(lambda_c) U_c^T  =>  noised precision P = U diag(1/(VA + S2 lambda)) U^T, log det = sum log(VA + S2 lambda)).
+// The precision is written directly as the split-f16 MFMA A-operand image the step loop multiplies with (layout of
+// k_pack_mlp: half index -> (to, kb, part, lane, j), element P[16 to + lane%16][16 (2 kb + j/4) + 4 (lane/16) + j%4]).
+// grid = N*K blocks of 256 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ref_full_tables(RefFullArgs a) {
+  __shared__ float invd[128];
+  __shared__ float red[256];
+  const int k = blockIdx.x / a.K, c = blockIdx.x % a.K;
+  const float S = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 9];
+  const float VA = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 10];
+  const float S2 = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 11];
+  const int KB = sd_kb(a.NT);
+  const int img_floats = a.NT * KB * 512;
+  float ls = 0.0f;
+  for (int j = threadIdx.x; j < 128; j += 256) {
+    float iv = 0.0f;
+    if (j < a.d) {
+      const float var = VA + S2 * a.eigvals[static_cast<size_t>(c) * a.d + j];
+      iv = 1.0f / var;
+      ls += logf(var);
+    }
+    invd[j] = iv;
+  }
+  red[threadIdx.x] = ls;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const size_t blk = static_cast<size_t>(k) * a.K + c;
+  if (threadIdx.x == 0) {
+    float wsum = 0.0f;
+    for (int i = 0; i < a.K; ++i) wsum += a.weights ? a.weights[i] : 1.0f;
+    a.consts[blk * 2 + 0] = 0.5f * red[0];
+    a.consts[blk * 2 + 1] = logf((a.weights ? a.weights[c] : 1.0f) / wsum);
+  }
+  for (int f = threadIdx.x; f < a.dpad; f += 256) a.means_out[blk * a.dpad + f] = f < a.d ? S * a.means[static_cast<size_t>(c) * a.d + f] : 0.0f;
+  const float* U = a.eigvecs + static_cast<size_t>(c) * a.d * a.d;
+  _Float16* img = reinterpret_cast<_Float16*>(a.images + blk * img_floats);
+  for (int idx = threadIdx.x; idx < img_floats * 2; idx += 256) {
+    const int j8 = idx & 7, lane = (idx >> 3) & 63, part = (idx >> 9) & 1, tb = idx >> 10;
+    const int kb = tb % KB, to = tb / KB;
+    const int o = 16 * to + (lane & 15);
+    const int i = 16 * (2 * kb + (j8 >> 2)) + 4 * (lane >> 4) + (j8 & 3);
+    float p = 0.0f;
+    if (o < a.d && i < a.d) {
+      const float* uo = U + static_cast<size_t>(o) * a.d;
+      const float* ui = U + static_cast<size_t>(i) * a.d;
+      for (int j = 0; j < a.d; ++j) p = __builtin_fmaf(uo[j] * invd[j], ui[j], p);
+    }
+    const _Float16 hi = static_cast<_Float16>(p);
+    img[idx] = part == 0 ? hi : static_cast<_Float16>((p - static_cast<float>(hi)) * 2048.0f);
+  }
+}
+
 // static tables of a diagonal Gaussian / mixture: tab[c][0][f] = loc, tab[c][1][f] = 1/scale^2;
 // consts[c] = (0.5*sum log var, log w_norm, sum log scale + d*log sqrt(2pi), log-mixture-prob)
 __global__ void __launch_bounds__(128) k_dist_tables(DistTabArgs a) {
@@ -544,6 +602,10 @@ int sd_launch_time_embed(const TimeEmbedArgs& a, int N, hipStream_t s) {
 }
 int sd_launch_ref_tables(const RefTabArgs& a, int N, hipStream_t s) {
   hipLaunchKernelGGL(k_ref_tables, dim3(N * a.K), dim3(128), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_ref_full_tables(const RefFullArgs& a, int N, hipStream_t s) {
+  hipLaunchKernelGGL(k_ref_full_tables, dim3(N * a.K), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_dist_tables(const DistTabArgs& a, hipStream_t s) {

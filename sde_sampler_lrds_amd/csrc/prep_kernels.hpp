@@ -30,6 +30,16 @@ struct RefTabArgs {
   float* same_var;  // [1]: 1.0 when every component has the same variance vector (then so has every noised marginal)
 };
 
+// full-covariance mixture reference (SDENG_REF_GMM_FULL): per step and component the noised precision as an MFMA image
+struct RefFullArgs {
+  int K, d, dpad, NT;
+  const float* coef;
+  const float *means, *eigvals, *eigvecs, *weights;
+  float* images;     // [N][K][NT*KB*512]  split-f16 A-operand image of P = U diag(1/(VA + S2 lambda)) U^T
+  float* means_out;  // [N][K][dpad]       S * mean (0 on pad features)
+  float* consts;     // [N][K][2]          (0.5 log det, log w)
+};
+
 struct DistTabArgs {
   int K, d, dpad;
   const float *loc, *scale, *weights;  // weights nullptr: single Gaussian
@@ -56,6 +66,7 @@ struct TerminalArgs {
 int sd_launch_pack(const PackArgs& a, hipStream_t s);
 int sd_launch_time_embed(const TimeEmbedArgs& a, int N, hipStream_t s);
 int sd_launch_ref_tables(const RefTabArgs& a, int N, hipStream_t s);
+int sd_launch_ref_full_tables(const RefFullArgs& a, int N, hipStream_t s);
 int sd_launch_dist_tables(const DistTabArgs& a, hipStream_t s);
 int sd_launch_dist_eval(const DistEvalArgs& a, hipStream_t s);
 int sd_launch_terminal(const TerminalArgs& a, hipStream_t s);

@@ -20,7 +20,7 @@ int sd_launch_cmcd_8(const CmcdArgs& a, int grid, hipStream_t s);
 int sd_launch_logreg_images(const float* X, const float* y, int n, int dw, int NT, float* image, float* y_pad, hipStream_t s);
 int sd_launch_pack_square(const float* P, const float* loc, int d, int NT, float* out, float* loc_pad, hipStream_t s);
 
-enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };
+enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4 };
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };
 
 typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
@@ -58,6 +58,12 @@ static const sim_launch_fn kSimTable[4][4][3][2] = {
 // for DIS (no reference, ScoreCtrl)
 static const sim_launch_fn kEuboTable[4][5] = {{SD_EUBO_ROW(SD_ENTRY, 1)}, {SD_EUBO_ROW(SD_ENTRY, 2)}, {SD_EUBO_ROW(SD_ENTRY, 4)}, {SD_EUBO_ROW(SD_ENTRY, 8)}};
 // in-loop logistic-regression score (ScoreCtrl on a LOGREG target, no reference): [tiles 1,2,4][form LIN, EM]
+#define SD_FULL_ROW(X, DT) X(DT, 4, 0, 0) X(DT, 4, 0, 1) X(DT, 4, 0, 3)
+SD_FULL_ROW(SD_DECLARE_SIM, 1)
+SD_FULL_ROW(SD_DECLARE_SIM, 2)
+SD_FULL_ROW(SD_DECLARE_SIM, 4)
+SD_FULL_ROW(SD_DECLARE_SIM, 8)
+static const sim_launch_fn kFullTable[4][3] = {{SD_FULL_ROW(SD_ENTRY, 1)}, {SD_FULL_ROW(SD_ENTRY, 2)}, {SD_FULL_ROW(SD_ENTRY, 4)}, {SD_FULL_ROW(SD_ENTRY, 8)}};
 static const sim_launch_fn kLogregTable[3][2] = {{SD_LOGREG_ROW(SD_ENTRY, 1)}, {SD_LOGREG_ROW(SD_ENTRY, 2)}, {SD_LOGREG_ROW(SD_ENTRY, 4)}};
 #define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
 static const sim_launch_fn kCtrlTable[4][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}, {SD_CTRL_ROW(SD_CENTRY, 8)}};
@@ -93,7 +99,7 @@ static size_t dist_floats(const sdeng_dist& ds, int dpad) {
 }
 
 struct Layout {
-  size_t wpack, temb, stheta, ref_tab, ref_consts, target, ref_dist, prior, rnd_init, trash, logz, cmcd, total;
+  size_t wpack, temb, stheta, ref_tab, ref_mean, ref_consts, target, ref_dist, prior, rnd_init, trash, logz, cmcd, total;
 };
 
 static bool make_layout(const sdeng_desc* d, Layout& L) {
@@ -104,7 +110,13 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.temb = o; o += align64(static_cast<size_t>(d->N + 1) * SD_H);  // CMCD evaluates the net at N+1 times
   L.stheta = o; o += align64(d->N + 1);
   const int K = d->ref.kind == SDENG_REF_NONE ? 0 : (d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k);
-  L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * K * 2 * dpad);
+  if (d->ref.kind == SDENG_REF_GMM_FULL) {  // precision images + noised means
+    L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * K * DT * sd_kb(DT) * 512 + 256);
+    L.ref_mean = o; o += align64(static_cast<size_t>(d->N) * K * dpad);
+  } else {
+    L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * K * 2 * dpad);
+    L.ref_mean = o;
+  }
   L.ref_consts = o; o += align64(static_cast<size_t>(d->N) * K * 2 + 1);  // + the shared-variance flag
   L.target = o; o += dist_floats(d->target, dpad);
   L.ref_dist = o; o += dist_floats(d->ref_dist, dpad);
@@ -441,6 +453,23 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     a.ref_tab = ws + L.ref_tab; a.ref_consts = ws + L.ref_consts;
     a.ref_same_var = ws + L.ref_consts + static_cast<size_t>(d->N) * K * 2;
     a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
+  } else if (d->ref.kind == SDENG_REF_GMM_FULL) {
+    const int K = d->ref.k;
+    rf = RF_GMM_FULL;
+    if (K < 1 || !d->ref.means_init || !d->ref.vars_init || !d->ref.eigvecs)
+      return fail(SDENG_E_INVALID, "full-covariance reference: null means / eigenvalues / eigenvectors or k < 1");
+    if (d->N > 0) {
+      RefFullArgs r;
+      r.K = K; r.d = d->d; r.dpad = dpad; r.NT = DT; r.coef = d->coef;
+      r.means = d->ref.means_init; r.eigvals = d->ref.vars_init; r.eigvecs = d->ref.eigvecs; r.weights = d->ref.weights;
+      r.images = ws + L.ref_tab; r.means_out = ws + L.ref_mean; r.consts = ws + L.ref_consts;
+      SD_HIP(sd_launch_ref_full_tables(r, d->N, s));
+    }
+    a.ref_k = K;
+    a.ref_tab = ws + L.ref_tab; a.ref_mean = ws + L.ref_mean; a.ref_consts = ws + L.ref_consts;
+    a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
+    const int piece = (DT > 4 ? DT / 2 : DT) * sd_kb(DT) * 512;  // floats per staged piece of an image (sim_kernel.hpp FULL_PIECE)
+    a.ref_share = (piece / 256 + SD_WAVES - 1) / SD_WAVES;
   } else if (d->ref.kind != SDENG_REF_NONE) {
     return fail(SDENG_E_UNSUPPORTED, "reference kind %d", d->ref.kind);
   }
@@ -477,7 +506,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
       return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels: a reference drift with a ClippedCtrl, or no reference with a Score/LerpCtrl "
                                        "(ref.kind %d, ctrl_kind %d)", d->ref.kind, d->net.ctrl_kind);
     if (sc == SC_LOGREG) return fail(SDENG_E_UNSUPPORTED, "compute_eubo kernels: no logistic-regression control score");
-    fn = kEuboTable[dt_index(DT)][rf != RF_NONE ? rf - 1 : 2 + sc];
+    fn = rf == RF_GMM_FULL ? kFullTable[dt_index(DT)][2] : kEuboTable[dt_index(DT)][rf != RF_NONE ? rf - 1 : 2 + sc];
     if (tr || tt) {  // cost at the data distribution: rnd0 = [log p_ref(x_in)] - log pi~(x_in)   (losses/oc.py:322, :536, :1003)
       SD_HIP(hipMemsetAsync(ws + L.rnd_init, 0, sizeof(float) * d->B, s));
       t.x = d->x_in; t.rnd = ws + L.rnd_init;
@@ -495,6 +524,9 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     if (lds > 160 * 1024)
       return fail(SDENG_E_UNSUPPORTED, "drift net + design matrix (%d rows x %d) need %zu bytes of LDS, 163840 available", a.lr.n_rows, d->d, lds);
     fn = kLogregTable[dt_index(DT)][d->form];
+  } else if (rf == RF_GMM_FULL) {
+    if (sc != SC_NONE) return fail(SDENG_E_UNSUPPORTED, "full-covariance reference together with a Score/LerpCtrl");
+    fn = kFullTable[dt_index(DT)][d->form];
   } else {
     fn = kSimTable[dt_index(DT)][rf][sc][d->form];
   }

@@ -97,6 +97,7 @@ struct SimArgs {
   int ref_kc;               //   components per staged piece of the table (>= ref_k: the whole table in one piece)
   const float* ref_tab;     // [N][K][2][dpad]
   const float* ref_consts;  // [N][K][2]  (0.5*sum log var, log w)
+  const float* ref_mean;      // RF_GMM_FULL: [N][K][dpad] noised means (ref_tab then holds the precision images [N][K][NT*KB*512])
   const float* ref_same_var;  // [1] 1.0: all components share one variance vector (written by k_ref_tables)
   float ref_c1;             // 0.5*d*log(2*pi)
   DistDev target;         // in-loop target score (ScoreCtrl / LerpCtrl / CMCD)

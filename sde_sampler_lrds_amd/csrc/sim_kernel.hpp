@@ -10,7 +10,7 @@
 #pragma once
 #include "sim_device.hpp"
 
-enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3 };  // GMM: K <= SD_KREG (responsibilities in registers)
+enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4 };  // GMM: K <= SD_KREG (responsibilities in registers); FULL: full covariances
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };  // LOGREG: no reference table slots, d <= 64 (LDS)
 
 // score part of the generative control (added to clip(net)):
@@ -65,9 +65,13 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   // (one LDS-DMA copy per WORKGROUP instead of every wave streaming the table from L2).  Its 8 waves then
   // walk rounds and steps in lock-step -- one barrier per table piece, reached by every wave: a wave whose tile index is
   // past the end computes on zeros with all stores masked, so trip counts are uniform by construction.
-  const int share = REF == RF_GMM_BIG ? __builtin_amdgcn_readfirstlane(a.ref_share) : 0;
+  const int share = (REF == RF_GMM_BIG || REF == RF_GMM_FULL) ? __builtin_amdgcn_readfirstlane(a.ref_share) : 0;
   float* sh_tab = lds + sd_lds_weight_floats(NT);
   const int sh_floats = sd_share_buf_floats(share);
+  // full-covariance mixtures: a component's precision image (NT*KB*512 floats) is staged in FULL_PP pieces of FULL_TO output
+  // tiles each (32 KiB at d = 128), piece after piece through the same two buffers
+  constexpr int FULL_PP = NT > 4 ? 2 : 1, FULL_TO = NT / FULL_PP, FULL_PIECE = FULL_TO * ((NT + 1) / 2) * 512;
+  static_assert(REF != RF_GMM_FULL || NT % FULL_PP == 0, "pieces hold whole output tiles");
   const int p = lane & 15, g = lane >> 4;
   constexpr bool lin = FORM == SDENG_FORM_LIN;
   constexpr bool eubo = FORM == SDENG_FORM_EUBO;  // noising direction (compute_eubo)
@@ -99,6 +103,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         __syncthreads();
         if (a.N > 0) dma_table_shared(a.ref_tab, sh_tab, min(a.ref_kc, a.ref_k) * 2 * dpad, share, wave, lane);
       }
+    }
+    if constexpr (REF == RF_GMM_FULL) {  // always workgroup-shared: piece 0 of the first precision image
+      __syncthreads();
+      if (a.N > 0) dma_table_shared(a.ref_tab, sh_tab, FULL_PIECE, share, wave, lane);
     }
 
     for (int k = 0; k < a.N; ++k) {  // EUBO: the host lays the rows out in iteration order (times T - s run backwards)
@@ -156,7 +164,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       const float* rcs = a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2;
       if constexpr (ref_lds) wait_dma();
       float resp[REF == RF_GMM ? SD_KREG : 1];
-      f32x4 rs[REF == RF_GMM_BIG ? NT : 1];
+      f32x4 rs[(REF == RF_GMM_BIG || REF == RF_GMM_FULL) ? NT : 1];
 #ifdef SD_DBG_NOREF
       if constexpr (REF == RF_GMM) { resp[0] = 1.0f; resp[1] = resp[2] = resp[3] = 0.0f; }
 #else
@@ -187,6 +195,61 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         } else {
           gmm_score<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, rs);
         }
+      }
+      if constexpr (REF == RF_GMM_FULL) {
+        // score_mog_full (distr/gauss.py:110-121): per component v = P (m - x) on the matrix pipe (P staged in LDS for the whole
+        // workgroup, split-f16 like the drift net), logit = log w - quad/2 - logdet/2 - c1 with quad = <m - x, v>, then the same
+        // online softmax as the diagonal path; the score is sum_c p_c v_c.
+        constexpr int KB = (NT + 1) / 2;
+        float m_run, l_run;
+        gmm_score_begin<NT>(rs, m_run, l_run);
+        const int n_pieces = a.N * a.ref_k * FULL_PP;
+        for (int c = 0; c < a.ref_k; ++c) {
+          const float* mc = a.ref_mean + (static_cast<size_t>(k) * a.ref_k + c) * dpad;
+          f16x8 dh[KB], dl[KB];
+          {
+            f32x4 dm[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dm[t] = load_tile4(mc, t, g) - x[t];
+            split_tiles<NT>(dm, dh, dl);
+          }
+          f32x4 v[NT];
+          float quad = 0.0f;
+#pragma unroll
+          for (int h = 0; h < FULL_PP; ++h) {
+            const int q = (k * a.ref_k + c) * FULL_PP + h;
+            wait_dma();
+            __syncthreads();
+            if (q + 1 < n_pieces)
+              dma_table_shared(a.ref_tab + static_cast<size_t>(q + 1) * FULL_PIECE, sh_tab + ((q + 1) & 1) * sh_floats, FULL_PIECE, share,
+                               wave, lane);
+            f32x4 out[FULL_TO], mx[FULL_TO];
+#pragma unroll
+            for (int o = 0; o < FULL_TO; ++o) out[o] = mx[o] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            dense_pre<KB, FULL_TO>(dh, dl, out, mx, reinterpret_cast<const f16x8*>(sh_tab + (q & 1) * sh_floats), lane);
+            fold_lo<FULL_TO>(out, mx);
+#pragma unroll
+            for (int o = 0; o < FULL_TO; ++o) {
+              const int t = h * FULL_TO + o;
+              v[t] = out[o];
+              const f32x4 dmt = load_tile4(mc, t, g) - x[t];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) quad = __builtin_fmaf(dmt[r], out[o][r], quad);
+            }
+          }
+          quad = group_sum(quad);
+          const float lp = rcs[c * 2 + 1] + (((-0.5f * quad) - a.ref_c1) - rcs[c * 2 + 0]);
+          const float m_new = fmaxf(m_run, lp);
+          const float so = expf(m_run - m_new);
+          const float pk = expf(lp - m_new);
+          l_run = l_run * so + pk;
+          m_run = m_new;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs[t][r] = __builtin_fmaf(pk, v[t][r], rs[t][r] * so);
+        }
+        gmm_score_end<NT>(rs, l_run);
       }
       float st = 1.0f;
       if constexpr (SC != SC_NONE) st = a.stheta ? a.stheta[k] : 1.0f;
@@ -232,7 +295,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
           if constexpr (REF == RF_GMM)
             rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
 #endif
-          if constexpr (REF == RF_GMM_BIG) rq = rs[t];
+          if constexpr (REF == RF_GMM_BIG || REF == RF_GMM_FULL) rq = rs[t];
           if constexpr (REF == RF_GAUSS) rq = gauss_score_tile<NT>(x, rtab, g, t);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -357,7 +420,7 @@ template <int NT, int REF, int SC, int FORM, int PAR>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM)) +
                            (SC == SC_LOGREG ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0) +
-                           (REF == RF_GMM_BIG ? sizeof(float) * 2 * sd_share_buf_floats(a.ref_share) : 0);
+                           ((REF == RF_GMM_BIG || REF == RF_GMM_FULL) ? sizeof(float) * 2 * sd_share_buf_floats(a.ref_share) : 0);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);

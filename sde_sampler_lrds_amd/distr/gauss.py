@@ -30,6 +30,49 @@ def score_gauss(x, means, variances):
     return -(x - means) / variances
 
 
+def log_prob_gaussian_full(x, means, covariances, precisions=None, covariances_log_det=None, return_precision_times_diff=False):
+    """distr/gauss.py:75-94 (host-side torch; the step loop uses the HIP kernel)."""
+    diff = x.unsqueeze(1) - means.unsqueeze(0)
+    if precisions is None:
+        ptd = torch.linalg.solve(covariances.unsqueeze(0), diff.unsqueeze(-1)).squeeze(-1)
+    else:
+        ptd = torch.matmul(precisions.unsqueeze(0), diff.unsqueeze(-1)).squeeze(-1)
+    lp = -0.5 * torch.sum(diff * ptd, dim=-1) - 0.5 * means.shape[-1] * math.log(2.0 * math.pi)
+    lp = lp - 0.5 * (torch.logdet(covariances) if covariances_log_det is None else covariances_log_det).unsqueeze(0)
+    return (lp, ptd) if return_precision_times_diff else lp
+
+
+def score_mog_full(x, weights, means, covariances, precisions=None, covariances_log_det=None):
+    """distr/gauss.py:110-121."""
+    weights = weights / weights.sum()
+    lp, ptd = log_prob_gaussian_full(x, means, covariances, precisions, covariances_log_det, return_precision_times_diff=True)
+    p = torch.softmax(torch.log(weights.unsqueeze(0)) + lp, dim=-1)
+    return -torch.sum(p.unsqueeze(-1) * ptd, dim=1)
+
+
+class GMMFull(Distribution):
+    """Mixture of full-covariance Gaussians (distr/gauss.py GMMFull): what a full-covariance reference is at t = 0.  Only the
+    log-density and score are needed on the simulate path (terminal cost); they are host-side torch."""
+
+    def __init__(self, dim, loc, cov=None, prec=None, cov_log_det=None, mixture_weights=None, **kwargs):
+        super().__init__(dim=dim, log_norm_const=0.0, **{k: v for k, v in kwargs.items() if k in ("n_reference_samples",)})
+        self.register_buffer("loc", loc, persistent=False)
+        if cov is not None:
+            self.register_buffer("cov", cov, persistent=False)
+            prec, cov_log_det = torch.linalg.inv(cov), torch.logdet(cov)
+        self.register_buffer("prec", prec, persistent=False)
+        self.register_buffer("cov_log_det", cov_log_det, persistent=False)
+        w = mixture_weights if mixture_weights is not None else torch.ones(loc.shape[0])
+        self.register_buffer("mixture_weights", w / w.sum(), persistent=False)
+
+    def unnorm_log_prob(self, x):
+        lp = log_prob_gaussian_full(x, self.loc, None, precisions=self.prec, covariances_log_det=self.cov_log_det)
+        return torch.logsumexp(torch.log(self.mixture_weights).unsqueeze(0) + lp, dim=-1, keepdim=True)
+
+    def score(self, x, *args, **kwargs):
+        return score_mog_full(x, self.mixture_weights, self.loc, None, precisions=self.prec, covariances_log_det=self.cov_log_det)
+
+
 class GMM(Distribution):
     def __init__(self, dim=2, loc=None, scale=None, mixture_weights=None, n_reference_samples=int(1e7), name=None,
                  domain_scale=5, domain_tol=1e-5, **kwargs):

@@ -214,10 +214,7 @@ def resolve_reference(reference_ctrl):
     if utils is None:
         raise UnsupportedByEngine("reference_ctrl is an opaque callable: pass RDS.reference_ctrl or a MarginalReference")
     if "means_init" in utils:
-        var = utils["variances_init"]
-        if isinstance(var, tuple) or var.dim() != 2:
-            raise UnsupportedByEngine("full-covariance mixture references have no HIP kernel yet")
-        return "gmm", utils
+        return "gmm", utils  # diagonal [K,d], full [K,d,d] or the eigen form (D, P): ref_desc picks the kernel
     if "x_init" in utils:
         var = utils["var_init"]
         if isinstance(var, tuple) or var.dim() != 1:
@@ -235,11 +232,32 @@ def ref_desc(kind, utils, device, keep) -> L.Ref:
         r.means_init = _dev_f32(utils["x_init"].reshape(-1), device, keep)
         r.vars_init = _dev_f32(utils["var_init"].reshape(-1), device, keep)
     else:
-        r.kind, r.k = L.REF_GMM_DIAG, int(utils["means_init"].shape[0])
+        var = utils["variances_init"]
+        r.k = int(utils["means_init"].shape[0])
         r.means_init = _dev_f32(utils["means_init"], device, keep)
-        r.vars_init = _dev_f32(utils["variances_init"], device, keep)
         r.weights = _dev_f32(utils["weights_init"], device, keep)
+        if isinstance(var, tuple) or var.dim() == 3:
+            # full covariances (score_mog_full): the kernel takes the eigen form (D, P) the reference also accepts
+            # (eq/sdes.py:228-238); covariance matrices are decomposed once per parameter version
+            if isinstance(var, tuple):
+                evals, evecs = var
+            else:
+                key = (var.data_ptr(), var._version)
+                hit = _EIGH_CACHE.get("last")
+                if hit is None or hit[0] != key:
+                    hit = (key, torch.linalg.eigh(var.detach().double()))
+                    _EIGH_CACHE["last"] = hit
+                evals, evecs = hit[1][0].float(), hit[1][1].float()
+            r.kind = L.REF_GMM_FULL
+            r.vars_init = _dev_f32(evals, device, keep)
+            r.eigvecs = _dev_f32(evecs, device, keep)
+        else:
+            r.kind = L.REF_GMM_DIAG
+            r.vars_init = _dev_f32(var, device, keep)
     return r
+
+
+_EIGH_CACHE = {}
 
 
 # ------------------------------------------------------------------------------------------------

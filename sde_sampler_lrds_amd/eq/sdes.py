@@ -87,24 +87,37 @@ class OU(TorchSDE):
         return mean, self.s(t) ** 2 * (self.sigma_sq(t) - self.sigma_sq(s))
 
     def marginal_params(self, t, x_init, var_init=None, is_mixture=False):
-        """Mean / variance of the noised Gaussian at time t (diagonal var_init only in this engine)."""
+        """Mean / (co)variance of the noised Gaussian at time t (eq/sdes.py:208-248): diagonal variances, full covariance
+        matrices ([..., d, d]) or the eigen form ``(D, P)`` (covariance = P diag(D) P^T), for which the result is
+        ``(precision, log det)``."""
         loc = self.s(t) * x_init
         var = self.s(t) ** 2 * self.sigma_sq(t)
         if var_init is not None:
-            if isinstance(var_init, tuple) or var_init.dim() > x_init.dim():
-                raise NotImplementedError("full-covariance references are not supported by the HIP engine")
+            if isinstance(var_init, tuple):
+                diag = var_init[0] + self.sigma_sq(t)
+                prec = torch.einsum("...ik,...k,...jk->...ij", var_init[1], 1.0 / diag, var_init[1]) / self.s(t) ** 2
+                log_det = torch.sum(torch.log(diag), dim=-1) + 2.0 * diag.shape[-1] * torch.log(self.s(t))
+                return loc, (prec, log_det)
+            if var_init.dim() > x_init.dim():
+                var = var * torch.eye(var_init.shape[-1], device=var_init.device)
             var = var + self.s(t) ** 2 * var_init
         return loc, var
 
     def marginal_distr(self, t, x_init, var_init=None):
         from sde_sampler_lrds_amd.distr.gauss import Gauss
         loc, var = self.marginal_params(t, x_init, var_init=var_init)
+        if isinstance(var, tuple) or var.dim() > loc.dim():
+            raise NotImplementedError("single full-covariance Gaussian references are not supported by the HIP engine")
         return Gauss(dim=x_init.shape[-1], loc=loc, scale=var.sqrt(), domain_tol=None)
 
     def marginal_gmm_distr(self, t, means_init, variances_init, weights_init=None):
-        from sde_sampler_lrds_amd.distr.gauss import GMM
+        from sde_sampler_lrds_amd.distr.gauss import GMM, GMMFull
         means, variances = self.marginal_params(t, means_init, var_init=variances_init, is_mixture=True)
         w = weights_init if weights_init is not None else torch.ones(means.shape[0], device=means.device) / means.shape[0]
+        if isinstance(variances, tuple):
+            return GMMFull(dim=means_init.shape[-1], loc=means, prec=variances[0], cov_log_det=variances[1], mixture_weights=w)
+        if variances.dim() == 3:
+            return GMMFull(dim=means_init.shape[-1], loc=means, cov=variances, mixture_weights=w)
         return GMM(dim=means_init.shape[-1], loc=means, scale=torch.sqrt(variances), mixture_weights=w, domain_tol=None)
 
     def log_snr(self, t):

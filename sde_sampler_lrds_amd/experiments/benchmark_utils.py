@@ -131,10 +131,11 @@ def make_model(solver_type, ref_type, loss_type, integrator_type, model_type, ti
 def fit_gmm(n_components, dataset, means_init=None, em_type="diag", max_iter=1000):
     """experiments/benchmark_utils.py:336-361: fit the mixture that becomes the learned reference of (L)RDS
     (``model.change_reference_type('gmm', weights=..., means=..., variances=...)``).  Host-side data preparation with
-    scikit-learn, like upstream; the engine's reference kernels take diagonal mixtures (``em_type='diag'``)."""
+    scikit-learn, like upstream; ``em_type='diag'`` gives [K,d] variances, ``em_type='full'`` covariance matrices [K,d,d]
+    (both have step-loop kernels)."""
     from sklearn.mixture import GaussianMixture
-    if em_type != "diag":
-        raise NotImplementedError("full-covariance references have no HIP kernel (distr/gauss.py:110-121 score_mog_full)")
+    if em_type not in ("diag", "full"):
+        raise NotImplementedError(f"covariance_type '{em_type}': the engine's reference kernels take 'diag' or 'full' mixtures")
     data = dataset.reshape(-1, dataset.shape[-1]).cpu().numpy()
     last = None
     for reg_covar in [1e-6, 5e-5, 1e-5, 5e-4, 1e-4, 5e-3, 1e-3, 5e-2, 1e-2]:
@@ -144,6 +145,9 @@ def fit_gmm(n_components, dataset, means_init=None, em_type="diag", max_iter=100
             weights = torch.from_numpy(gmm.weights_).float()
             means = torch.from_numpy(gmm.means_).float()
             variances = torch.from_numpy(gmm.covariances_).float()
+            if em_type == "full":  # upstream validates by constructing GMMFull: positive definite covariances
+                torch.linalg.cholesky(variances)
+                return weights, means, variances
             if bool(torch.isfinite(variances).all()) and bool((variances > 0).all()):
                 return weights, means, variances
         except Exception as e:  # noqa: BLE001  (upstream retries with the next regulariser on any failure)

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import torch
 
-from .distr.gauss import score_gauss, score_mog
+from .distr.gauss import score_gauss, score_mog, score_mog_full
 
 
 class MarginalReference(torch.nn.Module):
@@ -16,10 +16,11 @@ class MarginalReference(torch.nn.Module):
         super().__init__()
         assert ref_type in ("gaussian", "gmm", "default")
         self.sde, self.ref_type = sde, ref_type
-        self.reference_distr_utils = {k: v.float() for k, v in utils.items()}
+        self.reference_distr_utils = {k: (tuple(a.float() for a in v) if isinstance(v, tuple) else v.float()) for k, v in utils.items()}
 
     def to(self, *a, **k):
-        self.reference_distr_utils = {key: v.to(*a, **k) for key, v in self.reference_distr_utils.items()}
+        self.reference_distr_utils = {key: (tuple(e.to(*a, **k) for e in v) if isinstance(v, tuple) else v.to(*a, **k))
+                                      for key, v in self.reference_distr_utils.items()}
         return super().to(*a, **k)
 
     @property
@@ -33,6 +34,10 @@ class MarginalReference(torch.nn.Module):
         u = self.reference_distr_utils
         if "means_init" in u:
             loc, var = self.sde.marginal_params(t, u["means_init"], var_init=u["variances_init"], is_mixture=True)
+            if isinstance(var, tuple):  # eq/sdes.py:341-342
+                return score_mog_full(x, u["weights_init"], loc, None, precisions=var[0], covariances_log_det=var[1])
+            if var.dim() == 3:
+                return score_mog_full(x, u["weights_init"], loc, var)
             return score_mog(x, u["weights_init"], loc, var)
         loc, var = self.sde.marginal_params(t, u["x_init"], var_init=u["var_init"])
         return score_gauss(x, loc, var)

@@ -48,7 +48,9 @@ def build(c, device):
         ctrl = ClippedCtrl(base_model=_mlp(d), clip_model=m["clip_model"])
         ctrl.load_state_dict(c.params("ctrl."))
         if kind == "rds_gmm":
-            ref = MarginalReference(sde, "gmm", means_init=c["ref_means"], variances_init=c["ref_vars"], weights_init=c["ref_w"].clone())
+            cov_kind = m.get("cov", "diag")
+            variances = c["ref_cov"] if cov_kind == "full" else ((c["ref_D"], c["ref_P"]) if cov_kind == "eigen" else c["ref_vars"])
+            ref = MarginalReference(sde, "gmm", means_init=c["ref_means"], variances_init=variances, weights_init=c["ref_w"].clone())
         else:
             ref = MarginalReference(sde, "gaussian", x_init=c["ref_x_init"], var_init=c["ref_var_init"])
         cls = {"ei": oc.EIReferenceSDELoss, "ddpm_like": oc.DDPMLikeReferenceSDELoss, "em": oc.EMReferenceSDELoss}[m["integrator"]]

@@ -136,7 +136,7 @@ def pack_params(prefix, state):
 
 
 # ----------------------------------------------------------------------------- cases
-def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", beta_max=10.0, t_end=None):
+def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", beta_max=10.0, t_end=None, cov="diag"):
     """RDS with a diagonal-GMM reference (solver/oc.py:563-576), VP noising, basic model
     (conf/solver/vp_rds.yaml, conf/model/basic.yaml)."""
     torch.manual_seed(seed)
@@ -147,6 +147,16 @@ def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", b
     means = target.loc.clone() + 0.1 * torch.randn(K, d)
     variances = 0.5 * torch.ones(K, d) * (1.0 + 0.2 * torch.rand(K, d))
     weights = torch.ones(K)
+    cov_arrays = dict(ref_vars=variances)
+    if cov != "diag":  # full covariance matrices (score_mog_full, distr/gauss.py:110-121), or their (D, P) eigen form (eq/sdes.py:228-238)
+        A = torch.randn(K, d, d) / d ** 0.5
+        full = 0.3 * A @ A.transpose(-1, -2) + 0.4 * torch.eye(d)
+        weights = torch.rand(K) + 0.5
+        if cov == "full":
+            variances, cov_arrays = full, dict(ref_cov=full)
+        else:
+            D, P = torch.linalg.eigh(full)
+            variances, cov_arrays = (D, P), dict(ref_D=D, ref_P=P)
     ref_utils = dict(means_init=means, variances_init=variances, weights_init=weights)
     ref_distr = sde.marginal_gmm_distr(t=torch.tensor(0.0), **ref_utils)
     ref_ctrl = lambda t, x: sde.marginal_gmm_score(t=t, x=x, **ref_utils)  # noqa: E731
@@ -169,14 +179,14 @@ def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", b
         (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
             ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=ref_distr.log_prob))
     meta = dict(kind="rds_gmm", integrator=integrator, d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=beta_max,
-                sigma=1.0, T=1.0, clip_model=1e4, time_type=time_type)
+                sigma=1.0, T=1.0, clip_model=1e4, time_type=time_type, cov=cov)
     arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], u0=u0, ref0=r0,
                   tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights,
-                  ref_means=means, ref_vars=variances, ref_w=weights, **pack_params("ctrl.", sd(ctrl)))
+                  ref_means=means, ref_w=weights, **cov_arrays, **pack_params("ctrl.", sd(ctrl)))
     finish(name, meta, arrays, res, draws)
 
 
-def case_eubo_gmm(name, d, K, B, N, seed, integrator):
+def case_eubo_gmm(name, d, K, B, N, seed, integrator, cov="diag"):
     """compute_eubo of the RDS losses (losses/oc.py:298-362 EM, :512-568 EI): noising trajectories started at target
     samples, diagonal-GMM reference, same set-up as case_rds_gmm."""
     torch.manual_seed(seed)
@@ -185,6 +195,12 @@ def case_eubo_gmm(name, d, K, B, N, seed, integrator):
     ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
     means = target.loc.clone() + 0.1 * torch.randn(K, d)
     variances, weights = 0.5 * torch.ones(K, d), torch.ones(K)
+    cov_arrays = dict(ref_vars=variances)
+    if cov == "full":  # full covariance matrices (score_mog_full)
+        A = torch.randn(K, d, d) / d ** 0.5
+        variances = 0.3 * A @ A.transpose(-1, -2) + 0.4 * torch.eye(d)
+        weights = torch.rand(K) + 0.5
+        cov_arrays = dict(ref_cov=variances)
 
     def reference_ctrl(t, x):
         return sde.marginal_gmm_score(t, x, means, variances, weights)
@@ -201,9 +217,9 @@ def case_eubo_gmm(name, d, K, B, N, seed, integrator):
     xc = x0.clone()
     run_with_replay(seed, lambda: loss.compute_eubo(ts, xc, target.unnorm_log_prob, ref_distr.log_prob))
     meta = dict(kind="eubo_gmm", d=d, K=K, B=B, N=N, seed=seed, integrator=integrator, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0,
-                clip_model=1e4, draws=draws)
+                clip_model=1e4, draws=draws, cov=cov)
     arrays = dict(ts=ts, x0=x0, rnd=rnd, out_x=xc, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights,
-                  ref_means=means, ref_vars=variances, ref_w=weights, **pack_params("ctrl.", sd(ctrl)))
+                  ref_means=means, ref_w=weights, **cov_arrays, **pack_params("ctrl.", sd(ctrl)))
     save(name, meta, arrays)
 
 
@@ -862,10 +878,15 @@ CASES = {
     "rds_em_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=64, seed=17, sde_kind="vp", integrator="em"),
     "rds_ei_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=18, sde_kind="vp", integrator="ei"),
     "rds_ei_pbm_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=19, sde_kind="pbm", integrator="ei"),
+    # full-covariance mixture references (score_mog_full): covariance matrices, and the (D, P) eigen form
+    "rds_ei_gmm_fullcov_d128_k4": lambda n: case_rds_gmm(n, d=128, K=4, B=32, N=32, seed=101, cov="full"),
+    "rds_em_gmm_fullcov_d40_k3": lambda n: case_rds_gmm(n, d=40, K=3, B=48, N=48, seed=102, integrator="em", cov="full"),
+    "rds_ei_gmm_eigen_d16_k3": lambda n: case_rds_gmm(n, d=16, K=3, B=64, N=32, seed=103, cov="eigen"),
     # compute_eubo (noising direction) of the RDS losses
     "eubo_ei_gmm_d128_k4": lambda n: case_eubo_gmm(n, d=128, K=4, B=64, N=16, seed=61, integrator="ei"),
     "eubo_ei_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=62, integrator="ei"),
     "eubo_em_gmm_d16_k4": lambda n: case_eubo_gmm(n, d=16, K=4, B=64, N=64, seed=63, integrator="em"),
+    "eubo_ei_gmm_fullcov_d40_k3": lambda n: case_eubo_gmm(n, d=40, K=3, B=48, N=32, seed=66, integrator="ei", cov="full"),
     "eubo_dis_ei_d8": lambda n: case_eubo_dis(n, d=8, K=4, B=64, N=32, seed=64),
     "eubo_cmcd_gmm_d16": lambda n: case_eubo_cmcd(n, d=16, K=4, B=64, N=32, seed=65),
     # log-variance training evaluation (loss + gradients) of the RDS losses

@@ -18,11 +18,12 @@ SIM_CASES = [
     "rds_ei_gmm_d128_k4", "rds_ei_gmm_d128_k4_n256", "rds_ei_gmm_d128_k16", "rds_ei_gmm_d8_k4",
     "rds_ddpm_gmm_d16_snr", "rds_em_gmm_d16", "rds_em_vp_default_d16", "rds_ei_vp_default_d16",
     "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "cmcd_phi4_d100", "pis_logreg_d61", "dds_logreg_d61", "dis_ei_d8",
-    "dis_orig_lerp_d8",
+    "dis_orig_lerp_d8", "rds_ei_gmm_fullcov_d128_k4", "rds_em_gmm_fullcov_d40_k3", "rds_ei_gmm_eigen_d16_k3",
 ]
 
 
-EUBO_CASES = ["eubo_ei_gmm_d128_k4", "eubo_ei_gmm_d16_k4", "eubo_em_gmm_d16_k4", "eubo_dis_ei_d8", "eubo_cmcd_gmm_d16"]  # compute_eubo (noising direction)
+EUBO_CASES = ["eubo_ei_gmm_d128_k4", "eubo_ei_gmm_d16_k4", "eubo_em_gmm_d16_k4", "eubo_dis_ei_d8", "eubo_cmcd_gmm_d16",
+              "eubo_ei_gmm_fullcov_d40_k3"]  # compute_eubo (noising direction)
 
 
 EULER_CASES = ["euler_langevin_gmm_d16", "euler_langevin_phi4_d100", "euler_langevin_rings_d2", "euler_ou_vp_d40",
@@ -72,13 +73,19 @@ def run_oracle_eubo(c: Case, noise=None):
         with torch.no_grad():
             return orc.eubo_dis_ei(c["ts"], c["x0"], ctrl, sde, tgt.logp, prior.logp, noise or orc.PhiloxNoise(m["seed"]))
     ctrl = orc.Ctrl(c.params("ctrl."), "clipped", clip_model=m["clip_model"])
-    means, var, w = c["ref_means"], c["ref_vars"], c["ref_w"]
-    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
-    refd = orc.GMMDiag(loc0, torch.sqrt(v0), w)
+    means, w = c["ref_means"], c["ref_w"]
     fn = orc.eubo_ei_ref if m["integrator"] == "ei" else orc.eubo_em_ref
+    if m.get("cov", "diag") == "full":
+        cov = c["ref_cov"]
+        refd = orc.GMMFullCov(*sde.marginal_full(torch.tensor(0.0), means, cov), w)
+        ref_score = lambda t, x: orc.mog_score_full(x, w, *sde.marginal_full(t, means, cov))  # noqa: E731
+    else:
+        var = c["ref_vars"]
+        loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+        refd = orc.GMMDiag(loc0, torch.sqrt(v0), w)
+        ref_score = lambda t, x: orc.mog_score(x, w, *sde.marginal_diag(t, means, var))  # noqa: E731
     with torch.no_grad():
-        return fn(c["ts"], c["x0"], ctrl, sde, tgt.logp, refd.logp, lambda t, x: orc.mog_score(x, w, *sde.marginal_diag(t, means, var)),
-                  noise or orc.PhiloxNoise(m["seed"]))
+        return fn(c["ts"], c["x0"], ctrl, sde, tgt.logp, refd.logp, ref_score, noise or orc.PhiloxNoise(m["seed"]))
 
 
 def run_oracle(c: Case, noise=None, B=None):
@@ -93,14 +100,25 @@ def run_oracle(c: Case, noise=None, B=None):
         sde = make_sde(m)
         tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
         ctrl = orc.Ctrl(c.params("ctrl."), "clipped", clip_model=m["clip_model"])
-        means, var, w = c["ref_means"], c["ref_vars"], c["ref_w"]
+        means, w = c["ref_means"], c["ref_w"]
+        cov_kind = m.get("cov", "diag")
+        if cov_kind == "full":  # covariance matrices [K,d,d] (score_mog_full with linalg.solve)
+            cov = c["ref_cov"]
+            ref_score = lambda t, x: orc.mog_score_full(x, w, *sde.marginal_full(t, means, cov))  # noqa: E731
+            refd = orc.GMMFullCov(*sde.marginal_full(torch.tensor(0.0), means, cov), w)
+        elif cov_kind == "eigen":  # (D, P) form: precisions and log-determinants
+            D, P = c["ref_D"], c["ref_P"]
+            ref_score = lambda t, x: orc.mog_score_full_prec(x, w, *sde.marginal_eigen(t, means, D, P))  # noqa: E731
+            refd = orc.GMMFullPrec(*sde.marginal_eigen(torch.tensor(0.0), means, D, P), w)
+        else:
+            var = c["ref_vars"]
 
-        def ref_score(t, x):
-            loc, v = sde.marginal_diag(t, means, var)
-            return orc.mog_score(x, w, loc, v)
+            def ref_score(t, x):
+                loc, v = sde.marginal_diag(t, means, var)
+                return orc.mog_score(x, w, loc, v)
 
-        loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
-        refd = orc.GMMDiag(loc0, torch.sqrt(v0), w)
+            loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
+            refd = orc.GMMDiag(loc0, torch.sqrt(v0), w)
         if m["integrator"] == "em":
             out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score, noise)
         else:

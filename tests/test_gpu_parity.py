@@ -298,3 +298,59 @@ def test_extreme_shapes_match_oracle(gpu, d, K, B, N):
     assert x.shape == (B, d) and rnd.shape == (B, 1) and xs.shape == (N + 1, B, d)
     assert ex < tol and er < tol
     assert torch.equal(xs[0], x0) and torch.equal(xs[-1], x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,B,N,form", [(16, 3, 40, 12, "ei"), (40, 2, 33, 10, "em"), (128, 4, 48, 16, "ei"), (128, 3, 20000, 24, "ei")])
+def test_full_covariance_reference_matches_oracle(gpu, d, K, B, N, form):
+    """RDS with a FULL-covariance mixture reference (score_mog_full, distr/gauss.py:110-121; eq/sdes.py:329-345): precision images
+    staged per workgroup, P (m - x) on the matrix pipe.  Checked against the oracle's covariance-form restatement (linalg.solve per
+    step) under identical injected noise; the large case also checks reruns bit for bit and the Philox stream."""
+    from sde_sampler_lrds_amd.distr.gauss import ManyModes
+    from sde_sampler_lrds_amd.eq.sdes import VP
+    from sde_sampler_lrds_amd.experiments.baseline_configs import _net
+    from sde_sampler_lrds_amd.losses import oc
+    from sde_sampler_lrds_amd.models.reparam import ClippedCtrl
+    from sde_sampler_lrds_amd.reference import MarginalReference
+    torch.manual_seed(500 + d)
+    sde = VP(0.1, 10.0, 1.0, terminal_t=1.0)
+    target = ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
+    ctrl = ClippedCtrl(base_model=_net(d), clip_model=1e4)
+    means = target.loc.clone() + 0.1 * torch.randn(K, d)
+    A = torch.randn(K, d, d) / d ** 0.5
+    cov = 0.3 * A @ A.transpose(-1, -2) + 0.4 * torch.eye(d)
+    wts = torch.rand(K) + 0.5
+    ref = MarginalReference(sde, "gmm", means_init=means, variances_init=cov, weights_init=wts)
+    for m in (sde, target, ctrl, ref):
+        m.to(gpu)
+    cls = oc.EIReferenceSDELoss if form == "ei" else oc.EMReferenceSDELoss
+    loss = cls(ctrl, ctrl, sde=sde, method="lv", reference_ctrl=ref)
+    ts = torch.linspace(0.0, 1.0, N + 1, device=gpu)
+    x0 = torch.randn(B, d, generator=torch.Generator().manual_seed(d)).to(gpu)
+    pb = min(B, 48)
+    z = torch.randn(N, B, d, generator=torch.Generator().manual_seed(d + 1))
+    args = (target.unnorm_log_prob, ref.reference_distr.log_prob)
+    x, rnd, _ = loss.simulate(ts, x0, *args, noise=z.to(gpu))
+    osde = orc.VP(0.1, 10.0, 1.0, 1.0)
+    tgt = orc.GMMDiag(target.loc.cpu(), target.scale.cpu(), target.mixture_weights.cpu())
+    octrl = orc.Ctrl({k: v.detach().cpu() for k, v in ctrl.state_dict().items()}, "clipped", clip_model=1e4)
+    loc0, cov0 = osde.marginal_full(torch.tensor(0.0), means, cov)
+    refd = orc.GMMFullCov(loc0, cov0, wts.clone())
+    fn = orc.simulate_ei_ref if form == "ei" else orc.simulate_em_ref
+
+    def oracle(xstart):
+        with torch.no_grad():
+            return fn(ts.cpu(), xstart, octrl, osde, tgt.logp, refd.logp,
+                      lambda t, xx: orc.mog_score_full(xx, wts.clone(), *osde.marginal_full(t, means, cov)), orc.InjectedNoise(z[:, :pb]))[:2]
+
+    ox, ornd = oracle(x0[:pb].cpu())
+    tol = max(TOL, 10 * gc.rel_err(oracle(x0[:pb].cpu() * (1 + 1.2e-7))[0], ox))  # coarse grids amplify one ulp beyond 1e-6
+    scale = torch.stack([ornd.flatten().abs(), tgt.logp(ox).flatten().abs(), refd.logp(ox).flatten().abs()]).max(dim=0).values.clamp(min=1.0)
+    ex = gc.rel_err(x[:pb].cpu(), ox)
+    er = float(((rnd[:pb].cpu().flatten() - ornd.flatten()).abs() / scale).max())
+    print(f"full-covariance reference d={d} K={K} B={B} N={N} {form}: x_N {ex:.2e}, rnd {er:.2e} (tolerance {tol:.1e})")
+    assert ex < tol and er < tol
+    if B > 1000:
+        a = loss.simulate(ts, x0, *args)
+        b = loss.simulate(ts, x0, *args)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and bool(torch.isfinite(a[1]).all())

@@ -32,7 +32,7 @@ def test_struct_sizes_match_header_layout():
     # sizes the C compiler produces for the same field lists (checked once with hipcc: see DESIGN.md)
     assert ctypes.sizeof(L.Dist) == 56
     assert ctypes.sizeof(L.TimeEmbed) == 104
-    assert ctypes.sizeof(L.Ref) == 32
+    assert ctypes.sizeof(L.Ref) == 40
 
 
 def test_workspace_bytes_and_bad_descriptors_without_gpu():
@@ -60,7 +60,8 @@ def test_descriptor_compiles_on_host(name):
     assert net.w_in and net.t_embed.dim_out == 64
     kind, utils = E.resolve_reference(getattr(loss, "reference_ctrl", None))
     ref = E.ref_desc(kind, utils, "cpu", keep)
-    assert ref.kind in (L.REF_NONE, L.REF_GAUSS_DIAG, L.REF_GMM_DIAG)
+    assert ref.kind in (L.REF_NONE, L.REF_GAUSS_DIAG, L.REF_GMM_DIAG, L.REF_GMM_FULL)
+    assert (ref.kind == L.REF_GMM_FULL) == ("fullcov" in name or "eigen" in name) and bool(ref.eigvecs) == (ref.kind == L.REF_GMM_FULL)
     tgt = E.resolve_logp(b["args"][0])
     assert tgt is not None and E.dist_desc(tgt[0], "cpu", keep).kind != L.DIST_NONE
 
@@ -166,6 +167,19 @@ def test_fit_gmm_gives_a_diagonal_reference():
     w, m, v = fit_gmm(2, data)
     assert w.shape == (2,) and m.shape == (2, 3) and v.shape == (2, 3)
     assert abs(float(w.sum()) - 1.0) < 1e-5 and float(m.abs().mean()) > 2.0
+
+
+def test_fit_gmm_full_covariances():
+    from sde_sampler_lrds_amd.experiments.benchmark_utils import fit_gmm
+    g = torch.Generator().manual_seed(0)
+    L_ = torch.tensor([[1.0, 0.0, 0.0], [0.6, 0.8, 0.0], [0.0, 0.3, 0.5]])
+    data = torch.cat([torch.randn(3000, 3, generator=g) @ L_.T + 3.0, torch.randn(3000, 3, generator=g) * 0.5 - 3.0])
+    w, m, cov = fit_gmm(2, data, em_type="full")
+    assert cov.shape == (2, 3, 3) and torch.allclose(w.sum(), torch.tensor(1.0), atol=1e-5)
+    k = int(m[:, 0].argmax())
+    assert torch.allclose(cov[k], L_ @ L_.T, atol=0.12)
+    with pytest.raises(NotImplementedError):
+        fit_gmm(2, data, em_type="tied")
 
 
 def test_interpolate_states_equals_the_reference_bookkeeping():

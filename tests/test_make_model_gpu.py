@@ -69,7 +69,8 @@ def test_trainable_wrapper_evaluate_with_eubo_metrics(gpu):
 
 
 @pytest.mark.gpu
-def test_learned_reference_pipeline(gpu):
+@pytest.mark.parametrize("em_type", ["diag", "full"])
+def test_learned_reference_pipeline(gpu, em_type):
     """The LRDS recipe end to end on the engine: MALA chains on the target (HIP log-density / score) -> fit_gmm -> RDS with
     the fitted mixture as reference -> a few log-variance training steps -> evaluation with EUBO metrics."""
     from sde_sampler_lrds_amd.additions.hacking import TrainableWrapper
@@ -78,7 +79,8 @@ def test_learned_reference_pipeline(gpu):
     target = _make_target(details)
     data = mcmc_sample(gpu, target, target.loc.clone(), step_size=5e-2, n_chains_per_mode=32, dataset_length=8192, n_warmup_steps=64)
     assert data.shape == (8192, 8) and torch.isfinite(data).all()
-    weights, means, variances = fit_gmm(4, data, means_init=target.loc.cpu())
+    weights, means, variances = fit_gmm(4, data, means_init=target.loc.cpu(), em_type=em_type)
+    assert variances.dim() == (3 if em_type == "full" else 2)
     assert float((means - target.loc.cpu()).abs().max()) < 0.5  # the chains stayed on their modes
     model = make_model("vp-ref", "gmm", "lv", "ei", "base_zero_init", "uniform",
                        dict(means_ref=means, variances_ref=variances, weights_ref=weights), details,

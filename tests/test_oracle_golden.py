@@ -18,6 +18,10 @@ def test_simulate_matches_reference(name):
     c = gc.load(name)
     x, rnd = gc.run_oracle(c)
     tol = 2e-5 if name in ("cmcd_logreg_d61",) else TOL_SIM  # hand-coded logreg gradient vs autograd
+    if "fullcov" in name or "eigen" in name:
+        # x_N is bit-identical; the terminal log p_ref is torch's MultivariateNormal mixture upstream (Cholesky-based Mahalanobis
+        # term) and the restated quadratic form here: |log p| ~ 100-200 whose fp32 ulp is 1.5e-5, against |rnd| ~ 10-30
+        tol = 1e-5
     assert gc.rel_err(x, c["out_x"]) < tol
     assert gc.rel_err(x, c["xs_last2"][-1]) < tol
     assert gc.rel_err(rnd, c["rnd"]) < tol
