@@ -42,6 +42,14 @@ def log_prob_gaussian_full(x, means, covariances, precisions=None, covariances_l
     return (lp, ptd) if return_precision_times_diff else lp
 
 
+def score_gauss_full(x, means, covariances, precisions=None):
+    """distr/gauss.py:129-135."""
+    diff = x - means.unsqueeze(0)
+    if precisions is None:
+        return -torch.linalg.solve(covariances.unsqueeze(0), diff.unsqueeze(-1)).squeeze(-1)
+    return -torch.matmul(precisions.unsqueeze(0), diff.unsqueeze(-1)).squeeze(-1)
+
+
 def score_mog_full(x, weights, means, covariances, precisions=None, covariances_log_det=None):
     """distr/gauss.py:110-121."""
     weights = weights / weights.sum()

@@ -216,10 +216,7 @@ def resolve_reference(reference_ctrl):
     if "means_init" in utils:
         return "gmm", utils  # diagonal [K,d], full [K,d,d] or the eigen form (D, P): ref_desc picks the kernel
     if "x_init" in utils:
-        var = utils["var_init"]
-        if isinstance(var, tuple) or var.dim() != 1:
-            raise UnsupportedByEngine("full-covariance Gaussian references have no HIP kernel yet")
-        return "gaussian", utils
+        return "gaussian", utils  # diagonal [d], a covariance matrix [d,d] or its eigen form (D, P)
     raise UnsupportedByEngine("EBM ('nn') references need autograd inside the step: not on the HIP path")
 
 
@@ -227,6 +224,12 @@ def ref_desc(kind, utils, device, keep) -> L.Ref:
     r = L.Ref()
     if kind == "none":
         r.kind = L.REF_NONE
+    elif kind == "gaussian" and (isinstance(utils["var_init"], tuple) or utils["var_init"].dim() == 2):
+        # score_gauss_full (distr/gauss.py:129-135, eq/sdes.py:274-277) = the full-covariance mixture kernel with one component
+        var = utils["var_init"]
+        full = dict(means_init=utils["x_init"].reshape(1, -1), weights_init=torch.ones(1),
+                    variances_init=(var[0].unsqueeze(0), var[1].unsqueeze(0)) if isinstance(var, tuple) else var.unsqueeze(0))
+        return ref_desc("gmm", full, device, keep)
     elif kind == "gaussian":
         r.kind, r.k = L.REF_GAUSS_DIAG, 1
         r.means_init = _dev_f32(utils["x_init"].reshape(-1), device, keep)

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import torch
 
-from .distr.gauss import score_gauss, score_mog, score_mog_full
+from .distr.gauss import score_gauss, score_gauss_full, score_mog, score_mog_full
 
 
 class MarginalReference(torch.nn.Module):
@@ -40,4 +40,8 @@ class MarginalReference(torch.nn.Module):
                 return score_mog_full(x, u["weights_init"], loc, var)
             return score_mog(x, u["weights_init"], loc, var)
         loc, var = self.sde.marginal_params(t, u["x_init"], var_init=u["var_init"])
+        if isinstance(var, tuple):  # eq/sdes.py:274-277
+            return score_gauss_full(x, loc, None, precisions=var[0])
+        if var.dim() == 2:
+            return score_gauss_full(x, loc, var)
         return score_gauss(x, loc, var)

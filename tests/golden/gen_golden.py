@@ -378,7 +378,7 @@ def case_train_lv_pis(name, d, B, N, seed, dt):
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob))
 
 
-def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em"):
+def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em", full=False):
     """RDS with the default Gaussian reference (solver/oc.py:535-551): VP + IsotropicGauss prior, or
     PinnedBM + Delta prior (conf/solver/vp_rds.yaml, pbm_rds.yaml)."""
     torch.manual_seed(seed)
@@ -387,6 +387,9 @@ def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em"):
     if sde_kind == "vp":
         sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
         x_init, var_init = torch.zeros(d), torch.ones(d)
+        if full:  # ref_type='gaussian' with a covariance matrix (solver/oc.py:551-562, score_gauss_full distr/gauss.py:129-135)
+            A = torch.randn(d, d) / d ** 0.5
+            x_init, var_init = 0.5 * torch.randn(d), 0.4 * A @ A.T + 0.6 * torch.eye(d)
         ts = r_get_timesteps(0.0, 1.0, steps=N)
         x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
         sde_meta = dict(sde="vp", beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0)
@@ -407,7 +410,8 @@ def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em"):
                                                          compute_weights=True, return_traj=True, use_ema=False))
     (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
         ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=ref_distr.log_prob))
-    meta = dict(kind="rds_default", integrator=integrator, d=d, K=K, B=B, N=N, seed=seed, clip_model=1e4, **sde_meta)
+    meta = dict(kind="rds_default", integrator=integrator, d=d, K=K, B=B, N=N, seed=seed, clip_model=1e4, cov="full" if full else "diag",
+                **sde_meta)
     arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], tgt_loc=target.loc, tgt_scale=target.scale,
                   tgt_w=target.mixture_weights, ref_x_init=x_init, ref_var_init=var_init,
                   **pack_params("ctrl.", sd(ctrl)))
@@ -878,6 +882,7 @@ CASES = {
     "rds_em_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=64, seed=17, sde_kind="vp", integrator="em"),
     "rds_ei_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=18, sde_kind="vp", integrator="ei"),
     "rds_ei_pbm_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=19, sde_kind="pbm", integrator="ei"),
+    "rds_ei_gauss_fullcov_d40": lambda n: case_rds_default(n, d=40, K=4, B=48, N=32, seed=104, sde_kind="vp", integrator="ei", full=True),
     # full-covariance mixture references (score_mog_full): covariance matrices, and the (D, P) eigen form
     "rds_ei_gmm_fullcov_d128_k4": lambda n: case_rds_gmm(n, d=128, K=4, B=32, N=32, seed=101, cov="full"),
     "rds_em_gmm_fullcov_d40_k3": lambda n: case_rds_gmm(n, d=40, K=3, B=48, N=48, seed=102, integrator="em", cov="full"),

@@ -19,6 +19,7 @@ SIM_CASES = [
     "rds_ddpm_gmm_d16_snr", "rds_em_gmm_d16", "rds_em_vp_default_d16", "rds_ei_vp_default_d16",
     "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "cmcd_phi4_d100", "pis_logreg_d61", "dds_logreg_d61", "dis_ei_d8",
     "dis_orig_lerp_d8", "rds_ei_gmm_fullcov_d128_k4", "rds_em_gmm_fullcov_d40_k3", "rds_ei_gmm_eigen_d16_k3",
+    "rds_ei_gauss_fullcov_d40",
 ]
 
 
@@ -129,13 +130,23 @@ def run_oracle(c: Case, noise=None, B=None):
         tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
         ctrl = orc.Ctrl(c.params("ctrl."), "clipped", clip_model=m["clip_model"])
         xi, vi = c["ref_x_init"], c["ref_var_init"]
+        if m.get("cov", "diag") == "full":  # covariance matrix [d,d]: score_gauss_full (distr/gauss.py:129-135) with linalg.solve
+            def full_t(t):
+                loc, cv = sde.marginal_full(t, xi.unsqueeze(0), vi.unsqueeze(0))
+                return loc[0], cv[0]
 
-        def ref_score(t, x):
-            loc, v = sde.marginal_diag(t, xi, vi)
-            return orc.gauss_score(x, loc, v)
+            def ref_score(t, x):
+                loc, cv = full_t(t)
+                return -torch.linalg.solve(cv.unsqueeze(0), (x - loc.unsqueeze(0)).unsqueeze(-1)).squeeze(-1)
 
-        loc0, v0 = sde.marginal_diag(torch.tensor(0.0), xi, vi)
-        refd = orc.GaussDiag(loc0, v0.sqrt())
+            refd = orc.GaussFull(*full_t(torch.tensor(0.0)))
+        else:
+            def ref_score(t, x):
+                loc, v = sde.marginal_diag(t, xi, vi)
+                return orc.gauss_score(x, loc, v)
+
+            loc0, v0 = sde.marginal_diag(torch.tensor(0.0), xi, vi)
+            refd = orc.GaussDiag(loc0, v0.sqrt())
         if m["integrator"] == "em":
             out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score, noise)
         else:
