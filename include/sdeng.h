@@ -122,6 +122,10 @@ typedef struct sdeng_dist {
  *   x' = x + (coef[1] x + clip(coef[7] score_target(x), net.clip_score)) coef[4] + coef[2] (z coef[5])
  * (target.kind NONE: no score term).  rnd_out is zero-filled; xs_out carries the N+1 states. */
 #define SDENG_CTRL_NONE 3
+/* CancelDriftCtrl (models/reparam.py:120-145, conf/model/langevin_init.yaml): a ScoreCtrl that also cancels the SDE's drift,
+ *   u = clip(net) + coef[8] x + coef[7] (scale clip(score_target(x)) s_theta(t))
+ * with coef[8] = drift_coeff(t)/g(t), coef[7] = g(t)/2 at the net's time (use_rescaling; else drift_coeff/g^2 and 1/2). */
+#define SDENG_CTRL_CANCEL_DRIFT 4
 #define SDENG_HIDDEN 64
 
 typedef struct sdeng_time_embed { /* models/mlp.py:57-96 TimeEmbed */

@@ -244,7 +244,7 @@ static int prepare_net(const sdeng_desc* d, const Layout& L, float* ws, int DT, 
 static int score_kind(const sdeng_desc* d, int& sc) {
   sc = SC_NONE;
   if (d->net.ctrl_kind == SDENG_CTRL_CLIPPED) return 0;
-  if (d->net.ctrl_kind != SDENG_CTRL_SCORE && d->net.ctrl_kind != SDENG_CTRL_LERP)
+  if (d->net.ctrl_kind != SDENG_CTRL_SCORE && d->net.ctrl_kind != SDENG_CTRL_LERP && d->net.ctrl_kind != SDENG_CTRL_CANCEL_DRIFT)
     return fail(SDENG_E_UNSUPPORTED, "unknown ctrl_kind %d", d->net.ctrl_kind);
   if (d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_RINGS) sc = SC_GMM;  // rings: runtime branch of the d <= 16 kernel
   else if (d->target.kind == SDENG_DIST_PHI4) sc = SC_PHI4;

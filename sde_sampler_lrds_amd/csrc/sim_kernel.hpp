@@ -16,6 +16,7 @@ enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };  // LOGREG: no ref
 // score part of the generative control (added to clip(net)):
 //   ScoreCtrl (models/reparam.py:112-117):  scale*clip(score_pi(x)) * s_theta(t)
 //   LerpCtrl  (models/reparam.py:166-199):  g(t) * (scale*clip(lerp(score_prior, score_pi, t/T)) * s_theta(t))
+//   CancelDriftCtrl (models/reparam.py:120-145):  drift(t,x)/g(t) + g(t)/2 * (scale*clip(score_pi(x)) * s_theta(t))
 SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, float score_gain, float lerp_w,
                                 bool in_range) {
   const bool lerp = a.ctrl_kind == SDENG_CTRL_LERP;
@@ -28,6 +29,9 @@ SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, 
   float v = a.scale_score * sv;
   v = v * st;
   if (lerp) v = in_range ? score_gain * v : 0.0f;  // only the prior term can be non-zero on a pad feature
+  // CancelDriftCtrl (models/reparam.py:131-145): + drift/g + (g/2) score, both gains per step at the net's time.  Pad features
+  // carry Philox noise in their state (nothing else reads it), so the drift term must not leak it into the control
+  if (a.ctrl_kind == SDENG_CTRL_CANCEL_DRIFT) v = in_range ? lerp_w * xv + score_gain * v : 0.0f;
   return v;
 }
 

@@ -157,7 +157,7 @@ def net_desc(ctrl, device, keep) -> L.Net:
     """ClippedCtrl / ScoreCtrl / LerpCtrl around FourierMLP(4 layers, 64 channels, GELU) -> sdeng_net."""
     if _name(ctrl) == "AveragedModel":  # EMA wrapper (solver/oc.py:69-78)
         ctrl = ctrl.module
-    kinds = {"ClippedCtrl": L.CTRL_CLIPPED, "ScoreCtrl": L.CTRL_SCORE, "LerpCtrl": L.CTRL_LERP}
+    kinds = {"ClippedCtrl": L.CTRL_CLIPPED, "ScoreCtrl": L.CTRL_SCORE, "LerpCtrl": L.CTRL_LERP, "CancelDriftCtrl": L.CTRL_CANCEL_DRIFT}
     if _name(ctrl) not in kinds:
         raise UnsupportedByEngine(f"control wrapper {_name(ctrl)} has no HIP kernel")
     net = ctrl.base_model
@@ -297,7 +297,8 @@ def _transition_gains(sde, s, t, ddpm):
     raise UnsupportedByEngine(f"{n} has no closed-form EI/DDPM transition kernel")
 
 
-def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, alpha=None, sigma=None, train=False, dim=1, rescale=True) -> torch.Tensor:
+def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, cancel=None, ctrl_sde=None, alpha=None, sigma=None, train=False, dim=1,
+               rescale=True) -> torch.Tensor:
     """[N,16] fp32 table (column meaning: include/sdeng.h).  ``kind``: 'ei' | 'ddpm' | 'dis_ei' | 'em' |
     'time_reversal' | 'dds' | 'eubo_ei' | 'eubo_em'.  ``ts`` is a CPU tensor; every entry is produced by the reference's scalar formula."""
     ts = ts.detach().to("cpu", torch.float32)
@@ -383,10 +384,16 @@ def coef_table(kind, ts, sde=None, *, with_ref=False, lerp=False, alpha=None, si
             row[5] = sigma * beta_k
         else:
             raise ValueError(kind)
+        csde = ctrl_sde if ctrl_sde is not None else sde  # the control's own SDE (DDS has no loss-level SDE)
         if lerp:  # LerpCtrl: weight t/T (reparam.py:175) and gain g(t) (reparam.py:199), at the net's time
             t_net = row[0].clone()
-            row[7] = sde.diff(t_net, None)
-            row[8] = t_net / sde.terminal_t
+            row[7] = csde.diff(t_net, None)
+            row[8] = t_net / csde.terminal_t
+        if cancel is not None:  # CancelDriftCtrl (reparam.py:131-145): drift/g + (g/2) score, or drift/g^2 + score/2
+            t_net = row[0].clone()
+            g = csde.diff(t_net, None)
+            row[7] = 0.5 * g if cancel == "rescale" else 0.5
+            row[8] = csde.drift_coeff_t(t_net) / (g if cancel == "rescale" else torch.square(g))
         if with_ref:  # eq/sdes.py:228-229, 247
             s_tau = sde.s(tau)
             row[9], row[10], row[11] = s_tau, s_tau ** 2 * sde.sigma_sq(tau), s_tau ** 2

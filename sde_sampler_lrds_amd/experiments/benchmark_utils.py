@@ -16,7 +16,8 @@ from ..solver import oc
 from ..utils.common import get_timesteps
 
 solver_types = {"dds_orig": "dds", "pis_orig": "pis", "dis_orig": "dis", "cmcd": "cmcd", "vp-ref": "vp_rds", "pbm-ref": "pbm_rds"}
-model_types = {"target_informed_zero_init": "score", "target_informed_lerp_tempering": "lerp", "base_zero_init": "basic"}
+model_types = {"target_informed_zero_init": "score", "target_informed_lerp_tempering": "lerp", "base_zero_init": "basic",
+               "target_informed_langevin_init": "langevin_init"}
 
 # conf/solver/*.yaml -> (solver class, prior, sde, default model, default loss)
 _SOLVERS = {

@@ -38,7 +38,7 @@ def ctrl_batched(ctrl, t_unique: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     flat = x.reshape(M * B, d)
     t_rows = t_unique.repeat_interleave(B).view(-1, 1)
     name, net = type(ctrl).__name__, getattr(ctrl, "base_model", None)
-    if name not in ("ClippedCtrl", "ScoreCtrl", "LerpCtrl") or type(net).__name__ != "FourierMLP":
+    if name not in ("ClippedCtrl", "ScoreCtrl", "LerpCtrl", "CancelDriftCtrl") or type(net).__name__ != "FourierMLP":
         return ctrl(t_rows, flat)
     h = net.input_embed(flat) + net.timestep_embed(t_unique.view(-1, 1)).repeat_interleave(B, dim=0)
     for layer in net.hidden_layer:
@@ -46,12 +46,15 @@ def ctrl_batched(ctrl, t_unique: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     out = _clip(net.out_layer(net.activation(h)), ctrl.clip_model)
     if name == "ClippedCtrl":
         return out
-    if name == "ScoreCtrl":
+    if name in ("ScoreCtrl", "CancelDriftCtrl"):
         score = ctrl.scale_score * ctrl.clipped_target_score(t_rows, flat)
     else:
         score = ctrl.scale_score * ctrl.clipped_interpolated_score(t_rows, flat)
     if ctrl.score_model is not None:
         score = score * _clip(ctrl.score_model(t_unique.view(-1, 1)), ctrl.clip_model).repeat_interleave(B, dim=0)
+    if name == "CancelDriftCtrl":  # reparam.py:142-145
+        g, f = ctrl.sde.diff(t_rows, flat), ctrl.sde.drift(t_rows, flat)
+        return out + (f / g) + 0.5 * g * score if ctrl.use_rescaling else out + (f / torch.square(g)) + 0.5 * score
     return out + (ctrl.sde.diff(t_rows, flat) * score if name == "LerpCtrl" else score)
 
 
@@ -194,6 +197,17 @@ class BaseOCLoss:
         return self._cpu_sde
 
     def _coef(self, ts, device, **kw):
+        # per-step gains of the control wrapper itself (LerpCtrl: g(t) and t/T; CancelDriftCtrl: drift/g and g/2), whatever the loss
+        ctrl = getattr(self.generative_ctrl, "module", self.generative_ctrl)
+        cname = type(ctrl).__name__
+        if cname in ("LerpCtrl", "CancelDriftCtrl") and kw.get("kind", self.kind) not in ("cmcd", "cmcd_eubo"):
+            if cname == "LerpCtrl":
+                kw.setdefault("lerp", True)
+            else:
+                kw.setdefault("cancel", "rescale" if ctrl.use_rescaling else "plain")
+            if getattr(self, "_ctrl_sde_cpu", None) is None or self._ctrl_sde_cpu[0] is not ctrl.sde:
+                self._ctrl_sde_cpu = (ctrl.sde, E._cpu_sde(ctrl.sde))
+            kw["ctrl_sde"] = self._ctrl_sde_cpu[1]
         key = (ts.data_ptr(), ts._version, ts.numel(), str(device), tuple(sorted((k, str(v)) for k, v in kw.items())))
         hit = self._coef_cache.get(key)
         if hit is None:

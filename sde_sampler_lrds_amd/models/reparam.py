@@ -66,3 +66,24 @@ class LerpCtrl(ScoreCtrl):
         if self.score_model is not None:
             score = score * self.clipped_score_model(t, x)
         return self.clipped_base_model(t, x) + self.sde.diff(t, x) * score
+
+
+class CancelDriftCtrl(ScoreCtrl):
+    """Langevin initialisation (models/reparam.py:120-145): a ScoreCtrl that also subtracts the denoising SDE's drift,
+    base_model + drift(t,x)/g(t) + g(t)/2 * scale * clip(target_score) * clip(score_model(t))  (``use_rescaling``; otherwise
+    drift/g^2 + score/2)."""
+
+    def __init__(self, *args, sde, langevin_init: bool = True, use_rescaling: bool = True, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.sde, self.langevin_init, self.use_rescaling = sde, langevin_init, use_rescaling
+
+    def forward(self, t, x):
+        ctrl = self.clipped_base_model(t, x)
+        g, f = self.sde.diff(t, x), self.sde.drift(t, x)
+        score = self.scale_score * self.clipped_target_score(t, x)
+        if self.score_model is not None:
+            score = score * self.clipped_score_model(t, x)
+        if self.use_rescaling:
+            return ctrl + (f / g) + 0.5 * g * score
+        return ctrl + (f / torch.square(g)) + 0.5 * score
+

@@ -19,7 +19,7 @@ from ..distr.gauss import Gauss, GaussFull, IsotropicGauss
 from ..eq import sdes
 from ..losses import oc as losses
 from ..models.mlp import FourierMLP, TimeEmbed
-from ..models.reparam import ClippedCtrl, LerpCtrl, ScoreCtrl
+from ..models.reparam import CancelDriftCtrl, ClippedCtrl, LerpCtrl, ScoreCtrl
 from ..models import utils as mutils
 from ..reference import MarginalReference
 from ..utils.common import Results, clip_and_log, get_timesteps
@@ -38,6 +38,8 @@ def build_ctrl(model: str, dim: int, sde, prior, target):
                      last_weight_init=mutils.kaiming_uniform_zeros_)
     if model == "basic":
         return ClippedCtrl(base_model=net, clip_model=1e4)
+    if model not in ("score", "lerp", "langevin_init"):
+        raise NotImplementedError(f"model '{model}' (unet) has no HIP kernel")
     bias_init = mutils.init_bias_uniform_zeros if model == "score" else partial(mutils.init_bias_uniform_constant, val=1.0)
     sm = TimeEmbed(dim_out=1, activation=act, num_layers=4, channels=64, last_bias_init=bias_init,
                    last_weight_init=mutils.kaiming_uniform_zeros_)
@@ -47,6 +49,8 @@ def build_ctrl(model: str, dim: int, sde, prior, target):
         return ScoreCtrl(**common)
     if model == "lerp":
         return LerpCtrl(**common, sde=sde, prior_score=prior.score)
+    if model == "langevin_init":  # conf/model/langevin_init.yaml
+        return CancelDriftCtrl(**common, sde=sde, langevin_init=True)
     raise NotImplementedError(f"model '{model}' (langevin_init / unet) has no HIP kernel")
 
 

@@ -13,7 +13,7 @@ from sde_sampler_lrds_amd.distr.rings import Rings
 from sde_sampler_lrds_amd.eq.sdes import VP, ControlledLangevinSDE, ControlledSDE, LangevinSDE, PinnedBM, ScaledBM
 from sde_sampler_lrds_amd.losses import oc
 from sde_sampler_lrds_amd.models.mlp import FourierMLP, TimeEmbed
-from sde_sampler_lrds_amd.models.reparam import ClippedCtrl, LerpCtrl, ScoreCtrl
+from sde_sampler_lrds_amd.models.reparam import CancelDriftCtrl, ClippedCtrl, LerpCtrl, ScoreCtrl
 from sde_sampler_lrds_amd.reference import MarginalReference
 
 
@@ -88,7 +88,10 @@ def build(c, device):
         sde = make_sde(m)
         target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
         prior = IsotropicGauss(dim=d, scale=1.0)
-        if kind == "dis_ei":
+        if kind == "dis_ei" and m.get("cancel_drift"):
+            ctrl = CancelDriftCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                                   clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"], sde=sde)
+        elif kind == "dis_ei":
             ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
                              clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"])
         else:

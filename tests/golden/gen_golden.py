@@ -682,14 +682,19 @@ def case_logreg_ctrl(name, B, N, seed, solver):
     finish(name, meta, arrays, res, draws)
 
 
-def case_dis(name, d, K, B, N, seed, kind):
+def case_dis(name, d, K, B, N, seed, kind, cancel_drift=False):
     """DIS: kind='ei' -> DiscreteTimeReversalLossEI with ScoreCtrl; kind='orig' -> TimeReversalLoss with
     LerpCtrl (conf/solver/dis.yaml, conf/model/lerp.yaml, solver/oc.py:185-261)."""
     torch.manual_seed(seed)
     sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
     target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
     prior = r_gauss.IsotropicGauss(dim=d, scale=1.0)
-    if kind == "ei":
+    if kind == "ei" and cancel_drift:  # conf/model/langevin_init.yaml: CancelDriftCtrl (models/reparam.py:120-145)
+        ctrl = r_rep.CancelDriftCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0),
+                                     target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                                     scale_score=1.0, sde=sde, langevin_init=True)
+        loss = r_oc.DiscreteTimeReversalLossEI(ctrl, ctrl, sde=sde, method="kl")
+    elif kind == "ei":
         ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.2),
                                target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
                                scale_score=1.0)
@@ -708,7 +713,7 @@ def case_dis(name, d, K, B, N, seed, kind):
     (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
         ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, initial_log_prob=prior.log_prob, **kw))
     meta = dict(kind="dis_" + kind, d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0,
-                clip_model=1e4, clip_score=1e4, scale_score=1.0)
+                clip_model=1e4, clip_score=1e4, scale_score=1.0, cancel_drift=cancel_drift)
     arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], tgt_loc=target.loc, tgt_scale=target.scale,
                   tgt_w=target.mixture_weights, **pack_params("ctrl.", sd(ctrl)))
     finish(name, meta, arrays, res, draws)
@@ -931,6 +936,7 @@ CASES = {
     # DIS variants
     "dis_ei_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=51, kind="ei"),
     "dis_orig_lerp_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=64, seed=52, kind="orig"),
+    "dis_ei_cancel_drift_d8": lambda n: case_dis(n, d=8, K=4, B=64, N=32, seed=53, kind="ei", cancel_drift=True),
 }
 
 

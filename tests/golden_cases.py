@@ -19,7 +19,7 @@ SIM_CASES = [
     "rds_ddpm_gmm_d16_snr", "rds_em_gmm_d16", "rds_em_vp_default_d16", "rds_ei_vp_default_d16",
     "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "cmcd_phi4_d100", "pis_logreg_d61", "dds_logreg_d61", "dis_ei_d8",
     "dis_orig_lerp_d8", "rds_ei_gmm_fullcov_d128_k4", "rds_em_gmm_fullcov_d40_k3", "rds_ei_gmm_eigen_d16_k3",
-    "rds_ei_gauss_fullcov_d40",
+    "rds_ei_gauss_fullcov_d40", "dis_ei_cancel_drift_d8",
 ]
 
 
@@ -202,8 +202,8 @@ def run_oracle(c: Case, noise=None, B=None):
         tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
         prior = orc.IsoGauss(m["d"], 0.0, 1.0)
         if kind == "dis_ei":
-            ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score,
-                            clip_score=m["clip_score"], scale_score=m["scale_score"])
+            ctrl = orc.Ctrl(c.params("ctrl."), "cancel_drift" if m.get("cancel_drift") else "score", clip_model=m["clip_model"],
+                            target_score=tgt.score, clip_score=m["clip_score"], scale_score=m["scale_score"], sde=sde)
             out = orc.simulate_dis_ei(ts, x0, ctrl, sde, tgt.logp, prior.logp, noise)
         else:
             ctrl = orc.Ctrl(c.params("ctrl."), "lerp", clip_model=m["clip_model"], target_score=tgt.score,

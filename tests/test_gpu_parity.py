@@ -354,3 +354,58 @@ def test_full_covariance_reference_matches_oracle(gpu, d, K, B, N, form):
         a = loss.simulate(ts, x0, *args)
         b = loss.simulate(ts, x0, *args)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and bool(torch.isfinite(a[1]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wrapper", ["lerp", "cancel_drift"])
+@pytest.mark.parametrize("loss_kind", ["em", "dds", "dis_ei"])
+def test_control_wrappers_with_per_step_gains_in_every_loss(gpu, wrapper, loss_kind):
+    """LerpCtrl (g(t), t/T) and CancelDriftCtrl (drift/g, g/2) carry per-step gains of their own SDE; the fixtures pin them under
+    TimeReversalLoss / DiscreteTimeReversalLossEI, here they run under the EM loss (PIS form), DDS (whose loss has no SDE of its
+    own) and DIS-EI against the oracle, injected noise."""
+    from sde_sampler_lrds_amd.distr.gauss import GMM, IsotropicGauss
+    from sde_sampler_lrds_amd.eq.sdes import VP
+    from sde_sampler_lrds_amd.losses import oc
+    from sde_sampler_lrds_amd.models.mlp import FourierMLP, TimeEmbed
+    from sde_sampler_lrds_amd.models.reparam import CancelDriftCtrl, LerpCtrl
+    torch.manual_seed(7)
+    d, B, N = 8, 64, 32
+    sde = VP(0.1, 10.0, 1.0, terminal_t=1.0)
+    loc = 2.0 * torch.randn(3, d)
+    target = GMM(dim=d, loc=loc, scale=0.7 * torch.ones(3, d), mixture_weights=torch.tensor([0.5, 0.3, 0.2]))
+    prior = IsotropicGauss(dim=d, scale=1.0)
+    net = FourierMLP(dim=d, activation=torch.nn.GELU(), num_layers=4, channels=64)
+    sm = TimeEmbed(dim_out=1, activation=torch.nn.GELU(), num_layers=4, channels=64)
+    with torch.no_grad():
+        net.out_layer.weight.uniform_(-0.1, 0.1)
+        sm.out_layer.bias.fill_(0.7)
+    common = dict(base_model=net, score_model=sm, target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                  scale_score=1.0, sde=sde)
+    ctrl = LerpCtrl(**common, prior_score=prior.score) if wrapper == "lerp" else CancelDriftCtrl(**common)
+    for m in (sde, target, prior, ctrl):
+        m.to(gpu)
+    ts = torch.linspace(0.0, 1.0, N + 1, device=gpu)
+    x0 = torch.randn(B, d, generator=torch.Generator().manual_seed(1)).to(gpu)
+    z = torch.randn(N, B, d, generator=torch.Generator().manual_seed(2))
+    osde = orc.VP(0.1, 10.0, 1.0, 1.0)
+    tgt, opr = orc.GMMDiag(loc, 0.7 * torch.ones(3, d), torch.tensor([0.5, 0.3, 0.2])), orc.IsoGauss(d, 0.0, 1.0)
+    octrl = orc.Ctrl({k: v.detach().cpu() for k, v in ctrl.state_dict().items()}, wrapper, clip_model=1e4, target_score=tgt.score, clip_score=1e4,
+                     scale_score=1.0, sde=osde, prior_score=opr.score)
+    noise = orc.InjectedNoise(z)
+    with torch.no_grad():
+        if loss_kind == "em":
+            loss = oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv")
+            x, rnd, _ = loss.simulate(ts, x0, target.unnorm_log_prob, prior.log_prob, noise=z.to(gpu))
+            ox, ornd, _ = orc.simulate_em_ref(ts.cpu(), x0.cpu(), octrl, osde, tgt.logp, opr.logp, None, noise)
+        elif loss_kind == "dds":
+            loss = oc.ExponentialIntegratorSDELoss(ctrl, ctrl, sde=None, method="lv", alpha=1.0, sigma=1.0)
+            x, rnd, _ = loss.simulate(ts, x0, target.unnorm_log_prob, prior.log_prob, compute_ito_int=True, noise=z.to(gpu))
+            ox, ornd = orc.simulate_dds(ts.cpu(), x0.cpu(), octrl, 1.0, 1.0, tgt.logp, opr.logp, noise)[:2]
+        else:
+            loss = oc.DiscreteTimeReversalLossEI(ctrl, ctrl, sde=sde, method="lv")
+            x, rnd, _ = loss.simulate(ts, x0, target.unnorm_log_prob, initial_log_prob=prior.log_prob, train=False, noise=z.to(gpu))
+            ox, ornd = orc.simulate_dis_ei(ts.cpu(), x0.cpu(), octrl, osde, tgt.logp, opr.logp, noise)[:2]
+    scale = torch.stack([ornd.flatten().abs(), tgt.logp(ox).flatten().abs(), opr.logp(ox).flatten().abs()]).max(dim=0).values.clamp(min=1.0)
+    ex, er = gc.rel_err(x.cpu(), ox), float(((rnd.cpu().flatten() - ornd.flatten()).abs() / scale).max())
+    print(f"{wrapper} under {loss_kind}: x_N {ex:.2e}, rnd {er:.2e}")
+    assert ex < 5 * TOL and er < 5 * TOL and float(ox.abs().max()) < 1e3
