@@ -147,6 +147,17 @@ class TwoModes(GMM):
         super().__init__(dim=dim, loc=loc, scale=scale, mixture_weights=torch.FloatTensor([2.0, 1.0]), **kwargs)
 
 
+class BracketTwoModes(GMM):
+    """(2/3) N(-a 1, C_1) + (1/3) N(+a 1, C_2) with (C_1)_i = (C_2)_(dim-i) on a linear variance ladder (reference :522-553)."""
+
+    def __init__(self, dim=2, a=0.75, equilibrated=False, var_min=0.01, var_max=0.2, **kwargs):
+        loc = torch.stack([-a * torch.ones((dim,)), a * torch.ones((dim,))])
+        ladder = torch.linspace(var_min, var_max, dim)
+        scale = torch.sqrt(torch.stack([ladder, torch.flip(ladder, dims=(0,))]))
+        weights = torch.ones((2,)) / 2.0 if equilibrated else torch.FloatTensor([2, 1]) / 2.0
+        super().__init__(dim=dim, loc=loc, scale=scale, mixture_weights=weights, **kwargs)
+
+
 class ManyModes(GMM):
     """n_modes isotropic components, means U[-n, n]^d from a seeded generator, weights
     logspace(0, 1, n, base=factor) (reference :569-594)."""

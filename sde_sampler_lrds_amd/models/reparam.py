@@ -75,6 +75,8 @@ class CancelDriftCtrl(ScoreCtrl):
 
     def __init__(self, *args, sde, langevin_init: bool = True, use_rescaling: bool = True, **kwargs):
         super().__init__(*args, **kwargs)
+        if sde is None or getattr(sde, "noise_type", None) not in ("diagonal", "scalar"):  # reparam.py:125-126 (DDS has no SDE)
+            raise ValueError(f"Invalid sde for CancelDriftCtrl: {sde!r}")
         self.sde, self.langevin_init, self.use_rescaling = sde, langevin_init, use_rescaling
 
     def forward(self, t, x):

@@ -38,6 +38,8 @@ def test_make_model_rds_gmm_evaluate(gpu):
     ("dis_orig", "default", "em", "target_informed_lerp_tempering", "uniform", "many_modes", dict(sigma=1.0)),
     ("vp-ref", "default", "ddpm_like", "base_zero_init", "snr", "many_modes", dict(sigma=1.0)),
     ("pbm-ref", "default", "ei", "base_zero_init", "snr", "many_modes", dict(sigma=0.4472135954999579)),
+    ("pis_orig", "default", "em", "target_informed_langevin_init", "uniform", "bracket_two_modes", dict(sigma=0.4472135954999579)),
+    ("dis_orig", "default", "em", "target_informed_langevin_init", "uniform", "many_modes", dict(sigma=1.0)),
     ("cmcd", "default", "em", "target_informed_zero_init", "uniform", "many_modes", dict()),
     ("cmcd", "gaussian", "em", "target_informed_zero_init", "uniform", "many_modes", dict(mean=torch.zeros(8), var=3.0 * torch.ones(8))),
 ])
