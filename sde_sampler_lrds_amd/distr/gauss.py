@@ -80,6 +80,29 @@ class GMMFull(Distribution):
     def score(self, x, *args, **kwargs):
         return score_mog_full(x, self.mixture_weights, self.loc, None, precisions=self.prec, covariances_log_det=self.cov_log_det)
 
+    def sample(self, shape=None):
+        comp = D.Categorical(self.mixture_weights).sample(torch.Size(shape or ()))
+        cov = getattr(self, "cov", None)
+        tril = torch.linalg.cholesky(cov if cov is not None else torch.linalg.inv(self.prec))
+        z = torch.randn(*comp.shape, self.dim, device=self.loc.device)
+        return self.loc[comp] + torch.matmul(tril[comp], z.unsqueeze(-1)).squeeze(-1)
+
+
+class TwoModesFull(GMMFull):
+    """(2/3) N(-a 1, C) + (1/3) N(+a 1, C) with one full covariance C = Q diag(0.05 logspace) Q^T, Q from the QR factorisation of a
+    seeded random matrix (reference :469-505).  A target for the solvers whose control does not evaluate the target score inside
+    the step loop (RDS with a ClippedCtrl): its log-density enters the terminal cost only."""
+
+    def __init__(self, dim=2, a=1.0, centered=False, ill_conditioned="medium", rand_factor=5.0, seed_q=42, **kwargs):
+        assert ill_conditioned in ["medium", "hard"]
+        loc = torch.stack([-a * torch.ones((dim,)), a * torch.ones((dim,))])
+        if centered:
+            loc += (a / 3.0) * torch.ones((dim,))
+        q = torch.linalg.qr(rand_factor * torch.rand((dim, dim), generator=torch.Generator().manual_seed(seed_q)), mode="complete").Q
+        diag = 0.05 * torch.logspace(-2.0 if ill_conditioned == "hard" else -1.0, 0.0, dim)
+        cov = torch.matmul(q, torch.matmul(torch.diag(diag), q.T))
+        super().__init__(dim=dim, loc=loc, cov=torch.stack([cov, cov.clone()]), mixture_weights=torch.FloatTensor([2.0, 1.0]), **kwargs)
+
 
 class GMM(Distribution):
     def __init__(self, dim=2, loc=None, scale=None, mixture_weights=None, n_reference_samples=int(1e7), name=None,

@@ -9,7 +9,7 @@ from functools import partial
 
 import torch
 
-from ..distr.gauss import BracketTwoModes, ManyModes, TwoModes
+from ..distr.gauss import BracketTwoModes, ManyModes, TwoModes, TwoModesFull
 from ..distr.phi_four import PhiFour
 from ..distr.rings import Rings
 from ..solver import oc
@@ -34,6 +34,8 @@ def make_target_details(target_name, **kwargs):
     """experiments/benchmark_utils.py:41-93 (targets with a HIP kernel)."""
     if target_name == "two_modes":
         return dict(name=target_name, dim=kwargs.get("dim", 5), ill_conditioned=kwargs.get("ill_conditioned", "medium"), a=kwargs.get("a", 1.0))
+    if target_name == "two_modes_full":  # log-density only (terminal cost): solvers with a ClippedCtrl
+        return dict(name=target_name, dim=kwargs.get("dim", 5), ill_conditioned=kwargs.get("ill_conditioned", "medium"), a=kwargs.get("a", 1.0))
     if target_name == "bracket_two_modes":
         return dict(name=target_name, dim=kwargs.get("dim", 5), a=kwargs.get("a", 0.75))
     if target_name == "many_modes":
@@ -53,6 +55,8 @@ def _make_target(details):
         return ManyModes(**{"n_modes": 4, "dim": 8, "seed_loc": 42, "mixture_weight_factor": 3.0, "var": 0.5, "n_reference_samples": 10000, **d})
     if name == "two_modes":  # conf/target/two_modes.yaml
         return TwoModes(**{"dim": 2, "a": 1.0, "n_reference_samples": 10000, **d})
+    if name == "two_modes_full":  # conf/target/two_modes_full.yaml
+        return TwoModesFull(**{"dim": 5, "a": 1.0, "n_reference_samples": 16384, **d})
     if name == "bracket_two_modes":  # conf/target/bracket_two_modes.yaml
         return BracketTwoModes(**{"dim": 5, "a": 1.0, "n_reference_samples": 16384, **d})
     if name == "phi_four":  # conf/target/phi_four.yaml

@@ -40,6 +40,7 @@ def test_make_model_rds_gmm_evaluate(gpu):
     ("pbm-ref", "default", "ei", "base_zero_init", "snr", "many_modes", dict(sigma=0.4472135954999579)),
     ("pis_orig", "default", "em", "target_informed_langevin_init", "uniform", "bracket_two_modes", dict(sigma=0.4472135954999579)),
     ("dis_orig", "default", "em", "target_informed_langevin_init", "uniform", "many_modes", dict(sigma=1.0)),
+    ("vp-ref", "default", "ei", "base_zero_init", "uniform", "two_modes_full", dict(sigma=1.0)),  # full-covariance target: terminal cost via torch
     ("cmcd", "default", "em", "target_informed_zero_init", "uniform", "many_modes", dict()),
     ("cmcd", "gaussian", "em", "target_informed_zero_init", "uniform", "many_modes", dict(mean=torch.zeros(8), var=3.0 * torch.ones(8))),
 ])
