@@ -189,7 +189,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_hbm_bytes_per_launch": (2 * 128 + 1) * 4 * B,
-                         "kernel": "k_simulate<NT=8,REF=GMM,SC=NONE,FORM=LIN> (one launch = all sde_steps of the batch)",
+                         "kernel": f"k_simulate<NT=8,REF={'GMM' if a.modes <= 4 else 'GMM_BIG'},SC=NONE,FORM=LIN> (one launch = all sde_steps of the batch)",
                          "kernel_ms": k_ms, "algorithmic_flops_per_particle_step": flops_ps,
                          "note": "peak = dense FP32 MFMA/vector rate: results carry fp32 accuracy; the GEMMs are issued as a "
                                  "3-product f16-split on v_mfma_f32_16x16x32_f16 (3x the algorithmic FLOP on the f16 pipe)"},
