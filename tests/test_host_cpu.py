@@ -255,3 +255,58 @@ def test_sampler_refusals_and_pairings():
         ebm_mle.smc_sampler(x, t, None, 1, 1, st, use_pdds_weights=True, sde=None)
     with pytest.raises(ValueError):
         ebm_mle.smc_sampler(torch.zeros(3, 4, 2), t, None, 1, 1, st, per_noise_init=True, reweight_threshold=1.0)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/sde_sampler"), reason="the reference checkout only exists in the build container")
+def test_reference_objects_compile_to_descriptors():
+    """INTEGRATION.md, route 1: the drop-in loss classes are handed the REFERENCE's own objects (its VP, ClippedCtrl / ScoreCtrl around
+    its FourierMLP, its ManyModes / IsotropicGauss, a bound ``reference_ctrl`` with ``reference_distr_utils``).  Descriptor
+    compilation is host-side, so it is checked here: same coefficient table as with this package's classes, every object
+    recognised."""
+    import sys
+    import types
+    for n in ("wandb", "torchquad", "torchsde"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.path.insert(0, "/root/reference")
+    try:
+        from sde_sampler.distr import gauss as r_gauss
+        from sde_sampler.eq import sdes as r_sdes
+        from sde_sampler.models import mlp as r_mlp
+        from sde_sampler.models import reparam as r_rep
+    finally:
+        sys.path.remove("/root/reference")
+    from sde_sampler_lrds_amd.eq.sdes import VP
+    from sde_sampler_lrds_amd.losses import oc
+    d, K = 16, 3
+    r_sde = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0)
+    target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
+    prior = r_gauss.IsotropicGauss(dim=d, scale=1.0)
+    net = r_mlp.FourierMLP(dim=d, activation=torch.nn.GELU(), num_layers=4, channels=64)
+    sm = r_mlp.TimeEmbed(dim_out=1, activation=torch.nn.GELU(), num_layers=4, channels=64)
+
+    class FakeRDS:  # what solver/oc.py:563-592 leaves on the solver object
+        reference_distr_utils = dict(means_init=target.loc.clone(), variances_init=0.5 * torch.ones(K, d), weights_init=torch.ones(K))
+
+        def reference_ctrl(self, t, x):
+            return r_sde.marginal_gmm_score(t=t, x=x, **self.reference_distr_utils)
+
+    rds = FakeRDS()
+    ts = torch.linspace(0.0, 1.0, 9)
+    keep = []
+    for ctrl in (r_rep.ClippedCtrl(base_model=net, clip_model=1e4),
+                 r_rep.ScoreCtrl(base_model=net, score_model=sm, target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4),
+                 r_rep.LerpCtrl(base_model=net, score_model=sm, target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                                sde=r_sde, prior_score=prior.score)):
+        nd = E.net_desc(ctrl, "cpu", keep)
+        assert nd.ctrl_kind == {"ClippedCtrl": L.CTRL_CLIPPED, "ScoreCtrl": L.CTRL_SCORE, "LerpCtrl": L.CTRL_LERP}[type(ctrl).__name__]
+        tgt, lerp_prior = E.ctrl_target(ctrl)
+        assert (tgt is None) == (nd.ctrl_kind == L.CTRL_CLIPPED) and (lerp_prior is not None) == (nd.ctrl_kind == L.CTRL_LERP)
+    ctrl = r_rep.ClippedCtrl(base_model=net, clip_model=1e4)
+    loss = oc.EIReferenceSDELoss(ctrl, ctrl, sde=r_sde, method="lv", reference_ctrl=rds.reference_ctrl)
+    kind, utils = E.resolve_reference(loss.reference_ctrl)
+    assert kind == "gmm" and E.ref_desc(kind, utils, "cpu", keep).kind == L.REF_GMM_DIAG
+    mine = oc.EIReferenceSDELoss(ctrl, ctrl, sde=VP(0.1, 10.0, 1.0, terminal_t=1.0), method="lv", reference_ctrl=rds.reference_ctrl)
+    assert torch.equal(loss._coef(ts, "cpu", with_ref=True), mine._coef(ts, "cpu", with_ref=True))
+    res = E.resolve_logp(target.unnorm_log_prob)
+    assert res is not None and E.dist_desc(res[0], "cpu", keep).kind == L.DIST_GMM_DIAG
+    assert E.dist_desc(prior, "cpu", keep).kind == L.DIST_ISO_GAUSS
