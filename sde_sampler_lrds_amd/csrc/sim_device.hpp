@@ -439,9 +439,11 @@ SD_INLINE void gmm_score(const f32x4 (&x)[NT], const float* __restrict__ tab, co
 // feature tile is then assembled where it is consumed, sum_k p_k (m_k - x) / var_k, so no d-wide score array
 // stays live across the output layer.
 #define SD_KREG 4
-template <int NT>
+// KC = SD_KREG: the component count is known to be SD_KREG (the reference's default, 4 modes): no per-component guards
+template <int NT, int KC = 0>
 SD_INLINE void gmm_resp(const f32x4 (&x)[NT], const float* __restrict__ tab, const float* __restrict__ consts,
                         int cstride, int K, float c1, int g, float (&p)[SD_KREG]) {
+  if constexpr (KC == SD_KREG) K = SD_KREG;
   float lp[SD_KREG];
   float mx = -INFINITY;
 #pragma unroll
@@ -463,9 +465,10 @@ SD_INLINE void gmm_resp(const f32x4 (&x)[NT], const float* __restrict__ tab, con
   for (int k = 0; k < SD_KREG; ++k) p[k] *= inv;
 }
 
-template <int NT>
+template <int NT, int KC = 0>
 SD_INLINE f32x4 gmm_score_tile(const f32x4 (&x)[NT], const float* __restrict__ tab, int K, int g, const float (&p)[SD_KREG], int t) {
   constexpr int dpad = 16 * NT;
+  if constexpr (KC == SD_KREG) K = SD_KREG;
   f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < SD_KREG; ++k) {
@@ -482,9 +485,10 @@ SD_INLINE f32x4 gmm_score_tile(const f32x4 (&x)[NT], const float* __restrict__ t
 
 // The same when every component has the same variance vector (the reference's default initialisation, and then
 // true of every noised marginal): sum_k p_k (m_k - x)/var = (sum_k p_k m_k - x)/var, one fma per component and element.
-template <int NT>
+template <int NT, int KC = 0>
 SD_INLINE f32x4 gmm_score_tile_shared_var(const f32x4 (&x)[NT], const float* __restrict__ tab, int K, int g, const float (&p)[SD_KREG], int t) {
   constexpr int dpad = 16 * NT;
+  if constexpr (KC == SD_KREG) K = SD_KREG;
   f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < SD_KREG; ++k) {

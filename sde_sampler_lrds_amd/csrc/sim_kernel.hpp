@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   float* trash = a.trash + tid * 4;
   bool same_var = false;
   if constexpr (REF == RF_GMM) same_var = a.N > 0 && a.ref_same_var[0] != 0.0f;
+  const bool kfull = REF == RF_GMM && a.ref_k == SD_KREG;  // all SD_KREG components present: the unguarded instantiations
 
   // CUs first; shared-table mode: the round's wave-0 tile decides, so all 8 waves run the same rounds
   for (int tile = blockIdx.x + gridDim.x * wave; (share ? tile - static_cast<int>(gridDim.x) * wave : tile) < a.ntiles;
@@ -172,7 +173,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 #ifdef SD_DBG_NOREF
       if constexpr (REF == RF_GMM) { resp[0] = 1.0f; resp[1] = resp[2] = resp[3] = 0.0f; }
 #else
-      if constexpr (REF == RF_GMM) gmm_resp<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, resp);
+      if constexpr (REF == RF_GMM) {
+        if (kfull) gmm_resp<NT, SD_KREG>(x, rtab, rcs, 2, SD_KREG, a.ref_c1, g, resp);
+        else gmm_resp<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, resp);
+      }
 #endif
       if constexpr (REF == RF_GMM_BIG) {
         if (share) {
@@ -296,8 +300,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 #ifdef SD_DBG_NOREF
           if constexpr (REF == RF_GMM) rq = f32x4{resp[0], resp[0], resp[0], resp[0]};
 #else
-          if constexpr (REF == RF_GMM)
-            rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
+          if constexpr (REF == RF_GMM) {
+            if (kfull) rq = same_var ? gmm_score_tile_shared_var<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t) : gmm_score_tile<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t);
+            else rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
+          }
 #endif
           if constexpr (REF == RF_GMM_BIG || REF == RF_GMM_FULL) rq = rs[t];
           if constexpr (REF == RF_GAUSS) rq = gauss_score_tile<NT>(x, rtab, g, t);
