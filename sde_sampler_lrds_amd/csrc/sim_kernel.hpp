@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   bool same_var = false;
   if constexpr (REF == RF_GMM) same_var = a.N > 0 && a.ref_same_var[0] != 0.0f;
   const bool kfull = REF == RF_GMM && a.ref_k == SD_KREG;  // all SD_KREG components present: the unguarded instantiations
+  const bool kfast = kfull && same_var;
 
   // CUs first; shared-table mode: the round's wave-0 tile decides, so all 8 waves run the same rounds
   for (int tile = blockIdx.x + gridDim.x * wave; (share ? tile - static_cast<int>(gridDim.x) * wave : tile) < a.ntiles;
@@ -301,7 +302,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
           if constexpr (REF == RF_GMM) rq = f32x4{resp[0], resp[0], resp[0], resp[0]};
 #else
           if constexpr (REF == RF_GMM) {
-            if (kfull) rq = same_var ? gmm_score_tile_shared_var<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t) : gmm_score_tile<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t);
+            if (kfast) rq = gmm_score_tile_shared_var<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t);  // the reference's default reference: one test
+            else if (kfull) rq = gmm_score_tile<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t);
             else rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
           }
 #endif
