@@ -567,6 +567,9 @@ SD_INLINE void phi4_edges(const f32x4 (&x)[NT], int t, int g, int lane, float& l
 template <int NT>
 SD_INLINE void phi4_score(const f32x4 (&x)[NT], const DistDev& ds, int d, int g, int lane, f32x4 (&acc)[NT]) {
   const float coef = ds.p0 * static_cast<float>(d);
+  // one reciprocal per call instead of an IEEE division per element (~10 instructions each; the reference divides, the product
+  // with the rounded reciprocal differs from it by at most one ulp)
+  const float inv_coef = 1.0f / coef;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float le, re;
@@ -576,7 +579,7 @@ SD_INLINE void phi4_score(const f32x4 (&x)[NT], const DistDev& ds, int d, int g,
       const float xv = x[t][r];
       const float xl = (r == 0) ? le : x[t][r > 0 ? r - 1 : 0];
       const float xr = (r == 3) ? re : x[t][r < 3 ? r + 1 : 3];
-      float gr = (ds.p1 - xv * (1.0f - xv * xv)) / coef;
+      float gr = (ds.p1 - xv * (1.0f - xv * xv)) * inv_coef;
       gr = gr + coef * ((2.0f * xv - xr) - xl);
       acc[t][r] = feat_lt(t, r, 4 * g, d) ? (-ds.p2) * gr : 0.0f;
     }

@@ -17,22 +17,48 @@ enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };  // LOGREG: no ref
 //   ScoreCtrl (models/reparam.py:112-117):  scale*clip(score_pi(x)) * s_theta(t)
 //   LerpCtrl  (models/reparam.py:166-199):  g(t) * (scale*clip(lerp(score_prior, score_pi, t/T)) * s_theta(t))
 //   CancelDriftCtrl (models/reparam.py:120-145):  drift(t,x)/g(t) + g(t)/2 * (scale*clip(score_pi(x)) * s_theta(t))
-SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, float score_gain, float lerp_w,
-                                bool in_range) {
-  const bool lerp = a.ctrl_kind == SDENG_CTRL_LERP;
-  if (lerp) {  // torch.lerp(prior_score, target_score, w); IsotropicGauss.score = (loc - x)/scale^2
-    const float ps = (a.prior.p0 - xv) / (a.prior.p1 * a.prior.p1);
+// KIND and CLIP are compile-time here and chosen ONCE per tile by add_ctrl_score_tile: tested per element, these uniform
+// run-time conditions cost a scalar branch each (the step loop of the PIS kernel carried 100+ of them per step).
+template <int KIND, bool CLIP>
+SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, float score_gain, float lerp_w, bool in_range,
+                                float inv_prior_var) {
+  constexpr bool lerp = KIND == SDENG_CTRL_LERP;
+  if constexpr (lerp) {  // torch.lerp(prior_score, target_score, w); IsotropicGauss.score = (loc - x)/scale^2
+    const float ps = (a.prior.p0 - xv) * inv_prior_var;  // reciprocal once per tile, not a division per element
     const float df = sv - ps;
     sv = (lerp_w < 0.5f) ? ps + lerp_w * df : sv - df * (1.0f - lerp_w);
   }
-  if (a.clip_score > 0.0f) sv = clampf(sv, a.clip_score);
+  if constexpr (CLIP) sv = clampf(sv, a.clip_score);
   float v = a.scale_score * sv;
   v = v * st;
-  if (lerp) v = in_range ? score_gain * v : 0.0f;  // only the prior term can be non-zero on a pad feature
+  if constexpr (lerp) v = in_range ? score_gain * v : 0.0f;  // only the prior term can be non-zero on a pad feature
   // CancelDriftCtrl (models/reparam.py:131-145): + drift/g + (g/2) score, both gains per step at the net's time.  Pad features
   // carry Philox noise in their state (nothing else reads it), so the drift term must not leak it into the control
-  if (a.ctrl_kind == SDENG_CTRL_CANCEL_DRIFT) v = in_range ? lerp_w * xv + score_gain * v : 0.0f;
+  if constexpr (KIND == SDENG_CTRL_CANCEL_DRIFT) v = in_range ? lerp_w * xv + score_gain * v : 0.0f;
   return v;
+}
+template <int KIND, bool CLIP>
+SD_INLINE void add_ctrl_score_tile_k(const SimArgs& a, f32x4& u, const f32x4& sv, const f32x4& xv, float st, float score_gain, float lerp_w,
+                                     int t, int g4, int d) {
+  const float inv_prior_var = KIND == SDENG_CTRL_LERP ? 1.0f / (a.prior.p1 * a.prior.p1) : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    u[r] = u[r] + ctrl_score_term<KIND, CLIP>(a, sv[r], xv[r], st, score_gain, lerp_w, feat_lt(t, r, g4, d), inv_prior_var);
+}
+// u += score part of the control for one feature tile (one uniform dispatch per tile)
+SD_INLINE void add_ctrl_score_tile(const SimArgs& a, f32x4& u, const f32x4& sv, const f32x4& xv, float st, float score_gain, float lerp_w,
+                                   int t, int g4, int d) {
+  const bool clip = a.clip_score > 0.0f;
+  if (a.ctrl_kind == SDENG_CTRL_LERP) {
+    if (clip) add_ctrl_score_tile_k<SDENG_CTRL_LERP, true>(a, u, sv, xv, st, score_gain, lerp_w, t, g4, d);
+    else add_ctrl_score_tile_k<SDENG_CTRL_LERP, false>(a, u, sv, xv, st, score_gain, lerp_w, t, g4, d);
+  } else if (a.ctrl_kind == SDENG_CTRL_CANCEL_DRIFT) {
+    if (clip) add_ctrl_score_tile_k<SDENG_CTRL_CANCEL_DRIFT, true>(a, u, sv, xv, st, score_gain, lerp_w, t, g4, d);
+    else add_ctrl_score_tile_k<SDENG_CTRL_CANCEL_DRIFT, false>(a, u, sv, xv, st, score_gain, lerp_w, t, g4, d);
+  } else {
+    if (clip) add_ctrl_score_tile_k<SDENG_CTRL_SCORE, true>(a, u, sv, xv, st, score_gain, lerp_w, t, g4, d);
+    else add_ctrl_score_tile_k<SDENG_CTRL_SCORE, false>(a, u, sv, xv, st, score_gain, lerp_w, t, g4, d);
+  }
 }
 
 // PAR = 1 adds the parity-mode paths (injected noise, trajectory dump); PAR = 0 keeps them out of the step loop.
@@ -287,11 +313,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
           const int t = t0 + o;
+          if constexpr (SC != SC_NONE) add_ctrl_score_tile(a, u[o], ts[t], x[t], st, score_gain, lerp_w, t, 4 * g, d_dyn);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float uv = u[o][r];
-            if constexpr (SC != SC_NONE)
-              uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * g, d_dyn));
             if constexpr (eubo) uv = uv * c2;  // use_rescaling: generative_ctrl /= sde_diff (losses/oc.py:348-349); 1 for EI
             u[o][r] = uv;
             if constexpr (!eubo) su2 = __builtin_fmaf(uv, uv, su2);
@@ -403,13 +428,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
       f32x4 u[1];
       mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, u);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float uv = u[0][r];
-        if (a.clip_model > 0.0f) uv = clampf(uv, a.clip_model);
-        if constexpr (SC != SC_NONE)
-          uv = uv + ctrl_score_term(a, ts[t][r], x[t][r], st, score_gain, lerp_w, feat_lt(t, r, 4 * g, a.d));
-        u[0][r] = uv;
-      }
+      for (int r = 0; r < 4; ++r)
+        if (a.clip_model > 0.0f) u[0][r] = clampf(u[0][r], a.clip_model);
+      if constexpr (SC != SC_NONE) add_ctrl_score_tile(a, u[0], ts[t], x[t], st, score_gain, lerp_w, t, 4 * g, a.d);
       store_quad(a.x_out, trash, row, a.d, live, t, g, u[0]);
     }
   }

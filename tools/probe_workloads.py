@@ -9,6 +9,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sde_sampler_lrds_amd import _lib as L  # noqa: E402
+
+if os.environ.get("SDENG_LIB"):  # A/B against another build of the library
+    L.LIB_PATH = os.environ["SDENG_LIB"]
 from sde_sampler_lrds_amd.experiments.baseline_configs import build_cmcd_logreg, build_pis_phi4  # noqa: E402
 
 if __name__ == "__main__":
