@@ -89,19 +89,29 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
         if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + pv * w2_1mt;
       }
   }
+  // uniform run-time switches (clips on / off, control kind) are tested once per tile, never per element: a scalar branch per
+  // element stalls issue (sim_kernel.hpp, add_ctrl_score_tile)
+  // (d > 64 keeps the plain per-element clamps: that instantiation spills, and the tile-level form made it 7 % slower)
+  const bool clip_b = s.cmcd_clip > 0.0f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = b[t][r] * hg2;
-      if (s.cmcd_clip > 0.0f) v = clampf(v, s.cmcd_clip);
-      b[t][r] = v;
+  for (int t = 0; t < NT; ++t) {
+    b[t] = b[t] * hg2;
+    if constexpr (TWO) b2[t] = b2[t] * hg2;
+    if constexpr (NT <= 4) {
+      if (clip_b) clamp_tile_rare(b[t], s.cmcd_clip);
       if constexpr (TWO) {
-        float v2 = b2[t][r] * hg2;
-        if (s.cmcd_clip > 0.0f) v2 = clampf(v2, s.cmcd_clip);
-        b2[t][r] = v2;
+        if (clip_b) clamp_tile_rare(b2[t], s.cmcd_clip);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (clip_b) b[t][r] = clampf(b[t][r], s.cmcd_clip);
+        if constexpr (TWO) {
+          if (clip_b) b2[t][r] = clampf(b2[t][r], s.cmcd_clip);
+        }
       }
     }
+  }
 
   // ---- control ----
   f32x4 hid[SD_HT];
@@ -112,19 +122,34 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   for (int t = 0; t < NT; ++t) {
     f32x4 o[1];
     mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, o);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float uv = o[0][r];
-      if (s.clip_model > 0.0f) uv = clampf(uv, s.clip_model);
+    if constexpr (NT <= 4) {
+      if (s.clip_model > 0.0f) clamp_tile_rare(o[0], s.clip_model);
       if (s.ctrl_kind == SDENG_CTRL_SCORE) {
-        float sv = ts[t][r];
-        if (s.clip_score > 0.0f) sv = clampf(sv, s.clip_score);
-        float v = s.scale_score * sv;
-        v = v * st;
-        uv = uv + v;
+        f32x4 sv = ts[t];
+        if (s.clip_score > 0.0f) clamp_tile_rare(sv, s.clip_score);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s.scale_score * sv[r];
+          v = v * st;
+          o[0][r] = o[0][r] + v;
+        }
       }
-      u[t][r] = uv;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float uv = o[0][r];
+        if (s.clip_model > 0.0f) uv = clampf(uv, s.clip_model);
+        if (s.ctrl_kind == SDENG_CTRL_SCORE) {
+          float sv = ts[t][r];
+          if (s.clip_score > 0.0f) sv = clampf(sv, s.clip_score);
+          float v = s.scale_score * sv;
+          v = v * st;
+          uv = uv + v;
+        }
+        o[0][r] = uv;
+      }
     }
+    u[t] = o[0];
   }
 }
 

@@ -23,6 +23,18 @@ SD_INLINE float clampf(float v, float m) {
   return v;
 }
 
+// torch.clip of one feature tile with a bound that almost never binds (1e4 / 1e5 in every config): one compare per element into
+// a wave-wide mask, and the 4-instruction NaN-preserving clamp only when some lane is out of range or NaN
+SD_INLINE void clamp_tile_rare(f32x4& v, float m) {
+  bool out_of_range = false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out_of_range |= !(__builtin_fabsf(v[r]) <= m);
+  if (__builtin_amdgcn_ballot_w64(out_of_range) != 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = clampf(v[r], m);
+  }
+}
+
 SD_INLINE int feat(int t, int r, int g) { return 16 * t + 4 * g + r; }
 // feat(t, r, g) < d with the lane-dependent part (4g) on one side only: the compare takes a scalar operand,
 // so no per-element index register is ever materialised.
