@@ -46,15 +46,16 @@ __global__ void __launch_bounds__(SD_EULER_THREADS) k_euler(const SimArgs a) {
         f32x4 z;
         if (a.noise_in) z = load_quad(a.noise_in + static_cast<size_t>(k) * a.B * a.d, row, a.d, live, t, g);
         else z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, a.seed_lo, a.seed_hi);
+        f32x4 sv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (SC != SC_NONE) {  // clip(score * g^2/2): the bound rarely binds -- one test per tile (sim_device.hpp)
+          sv = ts[t] * c7;
+          if (a.clip_score > 0.0f) clamp_tile_rare(sv, a.clip_score);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool in_range = full_d || feat_lt(t, r, 4 * g, a.d);  // pad features stay exactly zero
           float drift = c1 * x[t][r];
-          if constexpr (SC != SC_NONE) {
-            float sv = ts[t][r] * c7;
-            if (a.clip_score > 0.0f) sv = clampf(sv, a.clip_score);
-            drift = drift + sv;
-          }
+          if constexpr (SC != SC_NONE) drift = drift + sv[r];
           const float xn = (x[t][r] + drift * c4) + c2 * (z[r] * c5);
           x[t][r] = in_range ? xn : 0.0f;
         }
