@@ -84,7 +84,7 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = feat_lt(t, r, 4 * g, s.d) ? (a.iso_loc - x[t][r]) * a.inv_iso_var : 0.0f;
+        const float pv = feat_live<NT>(t, r, 4 * g, s.d) ? (a.iso_loc - x[t][r]) * a.inv_iso_var : 0.0f;
         b[t][r] = ts[t][r] * w_t + pv * w_1mt;
         if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + pv * w2_1mt;
       }
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
         } else {
           z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, s.seed_lo, s.seed_hi);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) z[r] = feat_lt(t, r, 4 * g, s.d) ? z[r] : 0.0f;
+          for (int r = 0; r < 4; ++r) z[r] = feat_live<NT>(t, r, 4 * g, s.d) ? z[r] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -39,6 +39,11 @@ SD_INLINE int feat(int t, int r, int g) { return 16 * t + 4 * g + r; }
 // feat(t, r, g) < d with the lane-dependent part (4g) on one side only: the compare takes a scalar operand,
 // so no per-element index register is ever materialised.
 SD_INLINE bool feat_lt(int t, int r, int g4, int d) { return g4 < d - (16 * t + r); }
+// The same for a kernel with NT feature tiles: NT is the smallest of {1, 2, 4, 8} tiles covering d (sdeng_api.hip tiles_of), so for
+// NT >= 2 we know d > 8 NT and the first NT/2 tiles hold live features only -- no mask instructions there (t is a compile-time
+// constant after unrolling).
+template <int NT>
+SD_INLINE bool feat_live(int t, int r, int g4, int d) { return (NT >= 2 && 2 * t < NT) ? true : feat_lt(t, r, g4, d); }
 
 // the 4 registers of feature tile t for this lane from a dense vector
 SD_INLINE f32x4 load_tile4(const float* base, int t, int g) { return *reinterpret_cast<const f32x4*>(base + 16 * t + 4 * g); }
@@ -593,7 +598,7 @@ SD_INLINE void phi4_score(const f32x4 (&x)[NT], const DistDev& ds, int d, int g,
       const float xr = (r == 3) ? re : x[t][r < 3 ? r + 1 : 3];
       float gr = (ds.p1 - xv * (1.0f - xv * xv)) * inv_coef;
       gr = gr + coef * ((2.0f * xv - xr) - xl);
-      acc[t][r] = feat_lt(t, r, 4 * g, d) ? (-ds.p2) * gr : 0.0f;
+      acc[t][r] = feat_live<NT>(t, r, 4 * g, d) ? (-ds.p2) * gr : 0.0f;
     }
   }
 }

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         if constexpr (SC == SC_PHI4) {
           if (!full_d) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z[r] = feat_lt(t, r, 4 * g, d_dyn) ? z[r] : 0.0f;
+            for (int r = 0; r < 4; ++r) z[r] = feat_live<NT>(t, r, 4 * g, d_dyn) ? z[r] : 0.0f;
           }
         }
         return z;
