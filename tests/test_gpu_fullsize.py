@@ -118,6 +118,30 @@ def test_cfg4_cmcd_logreg_shard_65536x256(gpu):
     _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(ornd.abs().max()))), "cfg4")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [17, 33, 65, 96, 127])
+def test_pis_phi4_pad_boundaries(gpu, d):
+    """phi^4 lattice sizes just past a tile-count boundary (d = 17, 33, 65: the last tile holds one live feature), at a tile boundary
+    (96) and one short of full (127): the pad masks are only applied on tiles that can hold pads (sim_device.hpp feat_live), and the
+    lattice's neighbour coupling reads across the live / pad edge."""
+    import math
+    B, N = 300, 24
+    loss, ts, x0, args, kw, info = cfgs.build_pis_phi4(gpu, B, N, d=d)
+    loss.seed = 3
+    x, rnd, _ = loss.simulate(ts, x0, *args, **kw)
+    g, T = math.sqrt(0.2), 5.0
+    sde = orc.ScaledBM(g, T)
+    tgt = orc.PhiFour(0.1, 0.0, d, 20.0)
+    ctrl = orc.Ctrl(_sd(info["ctrl"]), "score", clip_model=1e4, target_score=tgt.score, clip_score=1e4, scale_score=1.0)
+    refd = orc.GaussDiag(torch.zeros(d), torch.full((d,), g * math.sqrt(T)))
+    with torch.no_grad():
+        ox, ornd, _ = orc.simulate_em_ref(ts.cpu(), x0[:64].cpu(), ctrl, sde, tgt.logp, refd.logp, None, orc.PhiloxNoise(3))
+    x_err = gc.rel_err(x[:64].cpu(), ox)
+    r_err = _rnd_err(rnd[:64], ornd, max(1.0, float(ornd.abs().max())))
+    print(f"pis phi4 d={d}: x_N {x_err:.2e}, rnd {r_err:.2e}")
+    assert x_err < 2e-4 and r_err < 2e-4 and bool(torch.isfinite(rnd).all())
+
+
 # ---- larger mixtures (K > 4): the workgroup-shared, double-buffered table copy -------------------------------------------
 # 1-4 LDS-DMA chunks per wave, idle DMA waves (K = 5), the exact 160 KiB LDS fit (d = 128, K = 32), tables staged in
 # 2 and 4 pieces per step (K = 40, 100), dpad < 128, ragged batches that leave waves and whole rounds without a tile.
