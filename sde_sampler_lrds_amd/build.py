@@ -17,19 +17,21 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 GEN = os.path.join(CSRC, "gen")
-OBJ = os.path.join(CSRC, "obj")
-LIB = os.path.join(PKG, "libsdeng.so")
+# experiment knobs: SDENG_OUT = another library path (its objects go to csrc/obj_<name>/), SDENG_PACKED=0/1 below
+LIB = os.environ.get("SDENG_OUT") or os.path.join(PKG, "libsdeng.so")
+OBJ = os.path.join(CSRC, "obj" if not os.environ.get("SDENG_OUT") else "obj_" + os.path.basename(LIB).split(".")[0])
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the integrator and log-weight updates must round like the reference's separate
 # torch ops (no silent a*b+c fusion); fused multiply-adds are written explicitly where wanted.
-# -packed-fp32-ops: no v_pk_{add,mul,fma}_f32.  With two waves per SIMD the -O3 build that used them produced
-# rare corrupt values (one 16-lane row, low half of a register pair) in the mixture-score phase: ~20 % of the
-# tiles of a 65 536 x 64 run differed between reruns, none with one wave per SIMD, -O1, -fno-slp-vectorize or this
-# flag (tools/probe_determinism.py, tools/probe_divergence.py; not reproduced in isolation by
-# tools/ubench/mfma_pk_hazard.hip).  Packed fp32 buys ~12 % per element at best on this part
-# (profiles/r01_ubench_valu_cost.log), so nothing is lost.  tests/test_gpu_fullsize.py guards rerun equality.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-command-line-argument",
-         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-command-line-argument"]
+# Packed fp32 (v_pk_{add,mul,fma}_f32).  Round 1 shipped with them disabled because the -O3 build that used them gave
+# corrupt values at two waves per SIMD; the cause was not the packed instructions but a write-after-read hazard between
+# an MFMA's SrcC and INLINE-ASM vector instructions the hazard recognizer cannot see (sim_device.hpp
+# split_pair; the flag only moved the schedule).  With the asm gone both settings are hazard-free
+# (tools/isa_hazard_scan.py, tests/test_build_cpu.py); SDENG_PACKED picks one for A/B runs.
+PACKED = os.environ.get("SDENG_PACKED", "0") == "1"
+if not PACKED:
+    FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 if os.environ.get("SDENG_DEFS"):  # experiment knob: extra -D flags (ablation builds)
     FLAGS += ["-D" + d for d in os.environ["SDENG_DEFS"].split()]
 if os.environ.get("SDENG_WAVES"):  # experiment knob: waves per workgroup (8 = 2 per SIMD, 4 = 1 per SIMD)

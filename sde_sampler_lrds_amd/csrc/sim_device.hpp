@@ -68,17 +68,35 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // One pair of values -> packed (hi, lo) halves in 6 instructions: v_cvt_pk_f16_f32 (round to nearest even), two
 // v_fma_mix_f32 that subtract the f16 halves from the fp32 values exactly (v*1.0 - hi with the f16 operand read in
-// place: no separate f16->f32 conversion), two scalings, one v_cvt_pk_f16_f32.  hipcc's own lowering of the same
-// expression takes 11 (it converts every half twice).  Plain asm, no side effects: the compiler may schedule and
-// merge these statements freely.
+// place: no separate f16->f32 conversion), two scalings, one v_cvt_pk_f16_f32.
+//
+// NO INLINE ASM HERE.  Round 1 wrote these four instructions as asm statements.  LLVM's hazard recognizer
+// runs its MFMA rules only for instructions it classifies as VALU; an INLINEASM node is not one, so the rule "a VALU
+// write of a VGPR that an XDL MFMA issued < 3 wait states earlier reads as SrcC" (GCNHazardRecognizer
+// checkMAIVALUHazards, 4-pass case) was never applied to them: wherever the allocator handed a just-dead accumulator
+// register to one of these statements, the v_cvt_pk / v_fma_mix overwrote it 0-2 wait states after the MFMA -- while
+// the MFMA's last pass (rows 12-15 = lanes 48-63) had not read it yet (tools/isa_hazard_scan.py finds the sites;
+// for every compiler-visible VALU writer hipcc emits the `s_nop 2`).  That was the "lanes 48-63, one register"
+// corruption at two waves per SIMD.  Written with builtins the same six instructions come out (the opaque SGPR 1.0
+// keeps fma(a, 1, -hi) from being folded to a subtraction, which would need two separate f16->f32 conversions), and
+// every one of them is visible to the hazard recognizer.  build.py runs the scan on each object as a guard.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+SD_INLINE float opaque_one() {
+  float one = 1.0f;
+  asm("" : "+s"(one));  // no instruction: only hides the constant from the optimizer (not volatile: CSE'd, one SGPR per kernel)
+  return one;
+}
 SD_INLINE void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
-  float d0, d1;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(a), "v"(hi));
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(b), "v"(hi));
+  const float one = opaque_one();
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  float d0 = __builtin_fmaf(a, one, -static_cast<float>(h[0]));
+  float d1 = __builtin_fmaf(b, one, -static_cast<float>(h[1]));
   d0 *= SD_LO_SCALE;
   d1 *= SD_LO_SCALE;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+  const f16x2 l = __builtin_convertvector(f32x2{d0, d1}, f16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 SD_INLINE void split8(const f32x4& t0, const f32x4& t1, f16x8& hi, f16x8& lo) {
