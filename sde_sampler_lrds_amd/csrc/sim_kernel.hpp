@@ -81,6 +81,15 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     }
   }
   __syncthreads();
+#ifdef SD_DBG_PRIO_HI47  // DESIGN 4a experiments: which wave of a SIMD is the victim of the packed-fp32 corruption?
+  if (wave >= 4) __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef SD_DBG_ONLY47
+  if (wave < 4) return;
+#endif
+#ifdef SD_DBG_ONLY03
+  if (wave >= 4) return;
+#endif
   static_assert(SC != SC_LOGREG || (REF == RF_NONE && NT <= 4), "in-loop logistic-regression score: no reference, d <= 64");
   const float* bias = a.wpack + sd_off_bias(NT);
   // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)

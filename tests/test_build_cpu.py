@@ -1,0 +1,44 @@
+"""Build-time guards of the HIP sources (CPU only: hipcc cross-compiles for gfx950 here).
+
+DESIGN 4a: LLVM's hazard recognizer cannot see vector instructions written as inline asm, so an asm statement must never
+contain one; and the emitted assembly of the headline unit is scanned for MFMA / asm adjacencies anyway."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sde_sampler_lrds_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_no_vector_instruction_in_inline_asm():
+    offenders = []
+    for name in sorted(os.listdir(CSRC)):
+        if not name.endswith((".hip", ".hpp")):
+            continue
+        text = open(os.path.join(CSRC, name)).read()
+        for m in re.finditer(r"asm\s*(?:volatile)?\s*\(\s*((?:\"[^\"]*\"\s*)+)", text):
+            body = "".join(re.findall(r"\"([^\"]*)\"", m.group(1)))
+            if re.search(r"\b(v_|ds_|global_|buffer_|flat_)\w+", body):
+                offenders.append((name, body.strip()[:60]))
+    assert not offenders, f"vector/memory instructions inside asm statements are invisible to the hazard recognizer: {offenders}"
+
+
+@pytest.mark.parametrize("unit", ["sim_8_2_0", "cmcd_4"])
+def test_isa_hazard_scan_is_clean(unit, tmp_path):
+    from isa_hazard_scan import scan
+
+    from sde_sampler_lrds_amd import build
+
+    build.sources()  # (re)generate csrc/gen
+    src = os.path.join(build.GEN, unit + ".hip")
+    out = str(tmp_path / (unit + ".s"))
+    r = subprocess.run([build.HIPCC, *build.FLAGS, "--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    assert "v_mfma_f32_16x16x32_f16" in text
+    assert "v_pk_fma_f32" not in text and "v_pk_mul_f32" not in text and "v_pk_add_f32" not in text, "packed fp32 must stay disabled (DESIGN 4a)"
+    assert scan(out, window=20, quiet=True) == []
