@@ -24,11 +24,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the integrator and log-weight updates must round like the reference's separate
 # torch ops (no silent a*b+c fusion); fused multiply-adds are written explicitly where wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-command-line-argument"]
-# Packed fp32 (v_pk_{add,mul,fma}_f32).  Round 1 shipped with them disabled because the -O3 build that used them gave
-# corrupt values at two waves per SIMD; the cause was not the packed instructions but a write-after-read hazard between
-# an MFMA's SrcC and INLINE-ASM vector instructions the hazard recognizer cannot see (sim_device.hpp
-# split_pair; the flag only moved the schedule).  With the asm gone both settings are hazard-free
-# (tools/isa_hazard_scan.py, tests/test_build_cpu.py); SDENG_PACKED picks one for A/B runs.
+# Packed fp32 (v_pk_{add,mul,fma}_f32) stays disabled.  With two waves per SIMD the build that uses them is not
+# reproducible on MI355X (the pre-empted wave of a SIMD gets wrong values; DESIGN 4a, profiles/r02_packed_fp32_hazard_experiments.log)
+# and it is slower anyway (6.11 vs 5.92 ms on cfg 2).  SDENG_PACKED=1 builds that variant for A/B runs only.
 PACKED = os.environ.get("SDENG_PACKED", "0") == "1"
 if not PACKED:
     FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
@@ -37,7 +35,8 @@ if os.environ.get("SDENG_DEFS"):  # experiment knob: extra -D flags (ablation bu
 if os.environ.get("SDENG_WAVES"):  # experiment knob: waves per workgroup (8 = 2 per SIMD, 4 = 1 per SIMD)
     FLAGS.append("-DSD_WAVES=" + os.environ["SDENG_WAVES"])
 
-DTS, REFS, SCS, FORMS = (1, 2, 4, 8), (0, 1, 2, 3), (0, 1, 2), (0, 1)  # DTS: feature tiles of 16
+DTS, REFS, SCS, FORMS = (1, 2, 3, 4, 5, 6, 7, 8), (0, 1, 2, 3), (0, 1, 2), (0, 1)  # DTS: feature tiles of 16, NT = ceil(d / 16)
+DTS_FULL = (1, 2, 3, 4, 6, 8)  # full-covariance reference: two staged pieces of NT/2 output tiles when NT > 4
 
 
 def sources():
@@ -49,11 +48,11 @@ def sources():
         _write_if_changed(path, '#include "../cmcd_kernel.hpp"\n'
                                 f"int sd_launch_cmcd_{dt}(const CmcdArgs& a, int grid, hipStream_t s) {{ return launch_cmcd<{dt}>(a, grid, s); }}\n")
         srcs.append(path)
-    for dt in (1, 2, 4):  # in-loop logistic-regression score (SC = 3): no reference, d <= 64, forward forms only
+    for dt in (1, 2, 3, 4):  # in-loop logistic-regression score (SC = 3): no reference, d <= 64, forward forms only
         path = os.path.join(GEN, f"sim_{dt}_0_3.hip")
         _write_if_changed(path, '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, 0, 3, {fm})\n" for fm in FORMS))
         srcs.append(path)
-    for dt in DTS:  # full-covariance mixture reference (REF = 4): ClippedCtrl; forward forms and the noising loop (3 = EUBO)
+    for dt in DTS_FULL:  # full-covariance mixture reference (REF = 4): ClippedCtrl; forward forms and the noising loop (3 = EUBO)
         path = os.path.join(GEN, f"sim_{dt}_4_0.hip")
         _write_if_changed(path, '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, 4, 0, {fm})\n" for fm in FORMS + (3,)))
         srcs.append(path)

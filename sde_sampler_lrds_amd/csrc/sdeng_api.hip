@@ -13,10 +13,11 @@
 #include "sim_common.hpp"
 #include "cmcd_kernel.hpp"
 
-int sd_launch_cmcd_1(const CmcdArgs& a, int grid, hipStream_t s);
-int sd_launch_cmcd_2(const CmcdArgs& a, int grid, hipStream_t s);
-int sd_launch_cmcd_4(const CmcdArgs& a, int grid, hipStream_t s);
-int sd_launch_cmcd_8(const CmcdArgs& a, int grid, hipStream_t s);
+#define SD_TILES(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8)      // feature tiles of 16: one instantiation per count (d <= 128)
+#define SD_TILES_LOGREG(M) M(1) M(2) M(3) M(4)                 // in-loop logistic-regression score: d <= 64 (design matrix in LDS)
+#define SD_TILES_FULL(M) M(1) M(2) M(3) M(4) M(6) M(8)          // full-covariance reference: 5 and 7 tiles run on 6 and 8 (piece staging)
+#define SD_DECLARE_CMCD(DT) int sd_launch_cmcd_##DT(const CmcdArgs& a, int grid, hipStream_t s);
+SD_TILES(SD_DECLARE_CMCD)
 int sd_launch_logreg_images(const float* X, const float* y, int n, int dw, int NT, float* image, float* y_pad, hipStream_t s);
 int sd_launch_pack_square(const float* P, const float* loc, int d, int NT, float* out, float* loc_pad, hipStream_t s);
 
@@ -26,47 +27,45 @@ enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };
 typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
 #define SD_DECLARE_SIM(DT, REF, SC, FORM) int sd_launch_sim_##DT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s);
 #define SD_DECLARE_CTRL(DT, SC) int sd_launch_ctrl_##DT##_##SC(const SimArgs& a, int grid, hipStream_t s);
+#define SD_ENTRY(DT, REF, SC, FORM) sd_launch_sim_##DT##_##REF##_##SC##_##FORM,
+#define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
+// forward forms (LIN, EM): [tiles - 1][reference kind 0..3][score kind 0..2][form]
 #define SD_FOR_FORM(M, DT, REF, SC) M(DT, REF, SC, 0) M(DT, REF, SC, 1)
 #define SD_FOR_SC(M, DT, REF) SD_FOR_FORM(M, DT, REF, 0) SD_FOR_FORM(M, DT, REF, 1) SD_FOR_FORM(M, DT, REF, 2)
 #define SD_FOR_REF(M, DT) SD_FOR_SC(M, DT, 0) SD_FOR_SC(M, DT, 1) SD_FOR_SC(M, DT, 2) SD_FOR_SC(M, DT, 3)
-SD_FOR_REF(SD_DECLARE_SIM, 1)
-SD_FOR_REF(SD_DECLARE_SIM, 2)
-SD_FOR_REF(SD_DECLARE_SIM, 4)
-SD_FOR_REF(SD_DECLARE_SIM, 8)
-#define SD_EUBO_ROW(M, DT) M(DT, 1, 0, 3) M(DT, 2, 0, 3) M(DT, 3, 0, 3) M(DT, 0, 1, 3) M(DT, 0, 2, 3)
-SD_EUBO_ROW(SD_DECLARE_SIM, 1)
-SD_EUBO_ROW(SD_DECLARE_SIM, 2)
-SD_EUBO_ROW(SD_DECLARE_SIM, 4)
-SD_EUBO_ROW(SD_DECLARE_SIM, 8)
-#define SD_LOGREG_ROW(M, DT) M(DT, 0, 3, 0) M(DT, 0, 3, 1)
-SD_LOGREG_ROW(SD_DECLARE_SIM, 1)
-SD_LOGREG_ROW(SD_DECLARE_SIM, 2)
-SD_LOGREG_ROW(SD_DECLARE_SIM, 4)
-#define SD_CTRL_ROW(M, DT) M(DT, 0) M(DT, 1) M(DT, 2)
-SD_CTRL_ROW(SD_DECLARE_CTRL, 1)
-SD_CTRL_ROW(SD_DECLARE_CTRL, 2)
-SD_CTRL_ROW(SD_DECLARE_CTRL, 4)
-SD_CTRL_ROW(SD_DECLARE_CTRL, 8)
-
-#define SD_ENTRY(DT, REF, SC, FORM) sd_launch_sim_##DT##_##REF##_##SC##_##FORM,
-static const sim_launch_fn kSimTable[4][4][3][2] = {
+#define SD_DECL_ALL(DT) SD_FOR_REF(SD_DECLARE_SIM, DT)
+SD_TILES(SD_DECL_ALL)
 #define SD_TAB_FORM(DT, REF, SC) {SD_ENTRY(DT, REF, SC, 0) SD_ENTRY(DT, REF, SC, 1)},
 #define SD_TAB_SC(DT, REF) {SD_TAB_FORM(DT, REF, 0) SD_TAB_FORM(DT, REF, 1) SD_TAB_FORM(DT, REF, 2)},
 #define SD_TAB_REF(DT) {SD_TAB_SC(DT, 0) SD_TAB_SC(DT, 1) SD_TAB_SC(DT, 2) SD_TAB_SC(DT, 3)},
-    SD_TAB_REF(1) SD_TAB_REF(2) SD_TAB_REF(4) SD_TAB_REF(8)};
-// compute_eubo kernels: [tiles][reference kind - 1] for the reference-SDE losses (ClippedCtrl), [tiles][2 + score kind]
+static const sim_launch_fn kSimTable[8][4][3][2] = {SD_TILES(SD_TAB_REF)};
+// compute_eubo kernels: [tiles - 1][reference kind - 1] for the reference-SDE losses (ClippedCtrl), [tiles - 1][2 + score kind]
 // for DIS (no reference, ScoreCtrl)
-static const sim_launch_fn kEuboTable[4][5] = {{SD_EUBO_ROW(SD_ENTRY, 1)}, {SD_EUBO_ROW(SD_ENTRY, 2)}, {SD_EUBO_ROW(SD_ENTRY, 4)}, {SD_EUBO_ROW(SD_ENTRY, 8)}};
-// in-loop logistic-regression score (ScoreCtrl on a LOGREG target, no reference): [tiles 1,2,4][form LIN, EM]
+#define SD_EUBO_ROW(M, DT) M(DT, 1, 0, 3) M(DT, 2, 0, 3) M(DT, 3, 0, 3) M(DT, 0, 1, 3) M(DT, 0, 2, 3)
+#define SD_DECL_EUBO(DT) SD_EUBO_ROW(SD_DECLARE_SIM, DT)
+SD_TILES(SD_DECL_EUBO)
+#define SD_TAB_EUBO(DT) {SD_EUBO_ROW(SD_ENTRY, DT)},
+static const sim_launch_fn kEuboTable[8][5] = {SD_TILES(SD_TAB_EUBO)};
+// in-loop logistic-regression score (ScoreCtrl on a LOGREG target, no reference): [tiles - 1][form LIN, EM]
+#define SD_LOGREG_ROW(M, DT) M(DT, 0, 3, 0) M(DT, 0, 3, 1)
+#define SD_DECL_LOGREG(DT) SD_LOGREG_ROW(SD_DECLARE_SIM, DT)
+SD_TILES_LOGREG(SD_DECL_LOGREG)
+#define SD_TAB_LOGREG(DT) {SD_LOGREG_ROW(SD_ENTRY, DT)},
+static const sim_launch_fn kLogregTable[4][2] = {SD_TILES_LOGREG(SD_TAB_LOGREG)};
+// full-covariance mixture reference: [tiles - 1][LIN, EM, EUBO]; 5 and 7 tiles have no instantiation (tiles_full rounds them up)
 #define SD_FULL_ROW(X, DT) X(DT, 4, 0, 0) X(DT, 4, 0, 1) X(DT, 4, 0, 3)
-SD_FULL_ROW(SD_DECLARE_SIM, 1)
-SD_FULL_ROW(SD_DECLARE_SIM, 2)
-SD_FULL_ROW(SD_DECLARE_SIM, 4)
-SD_FULL_ROW(SD_DECLARE_SIM, 8)
-static const sim_launch_fn kFullTable[4][3] = {{SD_FULL_ROW(SD_ENTRY, 1)}, {SD_FULL_ROW(SD_ENTRY, 2)}, {SD_FULL_ROW(SD_ENTRY, 4)}, {SD_FULL_ROW(SD_ENTRY, 8)}};
-static const sim_launch_fn kLogregTable[3][2] = {{SD_LOGREG_ROW(SD_ENTRY, 1)}, {SD_LOGREG_ROW(SD_ENTRY, 2)}, {SD_LOGREG_ROW(SD_ENTRY, 4)}};
-#define SD_CENTRY(DT, SC) sd_launch_ctrl_##DT##_##SC,
-static const sim_launch_fn kCtrlTable[4][3] = {{SD_CTRL_ROW(SD_CENTRY, 1)}, {SD_CTRL_ROW(SD_CENTRY, 2)}, {SD_CTRL_ROW(SD_CENTRY, 4)}, {SD_CTRL_ROW(SD_CENTRY, 8)}};
+#define SD_DECL_FULL(DT) SD_FULL_ROW(SD_DECLARE_SIM, DT)
+SD_TILES_FULL(SD_DECL_FULL)
+static const sim_launch_fn kFullTable[8][3] = {{SD_FULL_ROW(SD_ENTRY, 1)}, {SD_FULL_ROW(SD_ENTRY, 2)}, {SD_FULL_ROW(SD_ENTRY, 3)}, {SD_FULL_ROW(SD_ENTRY, 4)},
+                                               {nullptr, nullptr, nullptr}, {SD_FULL_ROW(SD_ENTRY, 6)}, {nullptr, nullptr, nullptr}, {SD_FULL_ROW(SD_ENTRY, 8)}};
+#define SD_CTRL_ROW(M, DT) M(DT, 0) M(DT, 1) M(DT, 2)
+#define SD_DECL_CTRL(DT) SD_CTRL_ROW(SD_DECLARE_CTRL, DT)
+SD_TILES(SD_DECL_CTRL)
+#define SD_TAB_CTRL(DT) {SD_CTRL_ROW(SD_CENTRY, DT)},
+static const sim_launch_fn kCtrlTable[8][3] = {SD_TILES(SD_TAB_CTRL)};
+typedef int (*cmcd_launch_fn)(const CmcdArgs&, int grid, hipStream_t);
+#define SD_TAB_CMCD(DT) sd_launch_cmcd_##DT,
+static const cmcd_launch_fn kCmcdTable[8] = {SD_TILES(SD_TAB_CMCD)};
 
 // ---- error string ------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -88,9 +87,15 @@ extern "C" const char* sdeng_last_error(void) { return g_err; }
 
 // ---- workspace layout ----------------------------------------------------------------------------
 static inline size_t align64(size_t n_floats) { return (n_floats + 63) & ~static_cast<size_t>(63); }
-// feature tiles of 16: instantiations exist for 1, 2, 4, 8 tiles (d <= 16, 32, 64, 128)
-static int tiles_of(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 64 ? 4 : 8)); }
-static int dt_index(int NT) { return NT == 1 ? 0 : (NT == 2 ? 1 : (NT == 4 ? 2 : 3)); }
+// feature tiles of 16: one instantiation per tile count, NT = ceil(d / 16) exactly (d = 100 runs 7 tiles, not 8: no vector or
+// matrix work on whole tiles of pad features).  The full-covariance reference kernels stage each precision image in two
+// pieces of NT/2 output tiles when NT > 4, so 5 and 7 tiles run on the 6- and 8-tile instantiations.
+static int tiles_exact(int d) { return (d + 15) / 16; }
+static int tiles_of(const sdeng_desc* d) {
+  const int nt = tiles_exact(d->d);
+  return (d->ref.kind == SDENG_REF_GMM_FULL && (nt == 5 || nt == 7)) ? nt + 1 : nt;
+}
+static int dt_index(int NT) { return NT - 1; }
 
 static size_t dist_floats(const sdeng_dist& ds, int dpad) {
   if (ds.kind == SDENG_DIST_GMM_DIAG) return align64(static_cast<size_t>(ds.k) * 2 * dpad) + align64(static_cast<size_t>(ds.k) * 4);
@@ -104,7 +109,7 @@ struct Layout {
 
 static bool make_layout(const sdeng_desc* d, Layout& L) {
   if (!d || d->d < 1 || d->d > 128 || d->N < 0 || d->B < 0) return false;
-  const int DT = tiles_of(d->d), dpad = 16 * DT;
+  const int DT = tiles_of(d), dpad = 16 * DT;
   size_t o = 0;
   L.wpack = o; o += align64(sd_pack_floats(DT));
   L.temb = o; o += align64(static_cast<size_t>(d->N + 1) * SD_H);  // CMCD evaluates the net at N+1 times
@@ -338,7 +343,7 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   a.target = target; a.prior = prior;
   c.s = a;
   if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
-  SD_HIP((DT == 1 ? sd_launch_cmcd_1 : (DT == 2 ? sd_launch_cmcd_2 : (DT == 4 ? sd_launch_cmcd_4 : sd_launch_cmcd_8)))(c, grid_for(a.ntiles), s));
+  SD_HIP(kCmcdTable[dt_index(DT)](c, grid_for(a.ntiles), s));
   if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
   // terminal: -log pi~(x_N)  (:752), or for the noising loop + log p_prior(x_noised)  (:825)
   if (eubo) { t.ref = prior; t.target = prior; t.use_ref = 1; t.use_target = 0; }
@@ -348,10 +353,11 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   return 0;
 }
 
-int sd_launch_euler_1(const SimArgs& a, int sc, hipStream_t s);
-int sd_launch_euler_2(const SimArgs& a, int sc, hipStream_t s);
-int sd_launch_euler_4(const SimArgs& a, int sc, hipStream_t s);
-int sd_launch_euler_8(const SimArgs& a, int sc, hipStream_t s);
+typedef int (*euler_launch_fn)(const SimArgs&, int sc, hipStream_t);
+#define SD_DECLARE_EULER(DT) int sd_launch_euler_##DT(const SimArgs& a, int sc, hipStream_t s);
+SD_TILES(SD_DECLARE_EULER)
+#define SD_TAB_EULER(DT) sd_launch_euler_##DT,
+static const euler_launch_fn kEulerTable[8] = {SD_TILES(SD_TAB_EULER)};
 
 // SDENG_CTRL_NONE: Euler-Maruyama of an SDE without a drift net (euler_kernel.hpp)
 static int simulate_euler(const sdeng_desc* d, const Layout& L, float* ws, int DT, SimArgs& a, hipStream_t s) {
@@ -371,12 +377,7 @@ static int simulate_euler(const sdeng_desc* d, const Layout& L, float* ws, int D
   a.target = target;
   a.clip_score = d->net.clip_score;
   if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
-  switch (DT) {
-    case 1: rc = sd_launch_euler_1(a, sc, s); break;
-    case 2: rc = sd_launch_euler_2(a, sc, s); break;
-    case 4: rc = sd_launch_euler_4(a, sc, s); break;
-    default: rc = sd_launch_euler_8(a, sc, s); break;
-  }
+  rc = kEulerTable[dt_index(DT)](a, sc, s);
   SD_HIP(rc);
   if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
   return 0;
@@ -396,7 +397,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM && d->form != SDENG_FORM_CMCD && d->form != SDENG_FORM_EUBO &&
       d->form != SDENG_FORM_CMCD_EUBO)
     return fail(SDENG_E_INVALID, "unknown form %d", d->form);
-  const int DT = tiles_of(d->d), dpad = 16 * DT;
+  const int DT = tiles_of(d), dpad = 16 * DT;
   float* ws = static_cast<float*>(d->workspace);
 
   SimArgs a;
@@ -557,7 +558,7 @@ extern "C" int sdeng_ctrl_forward(const sdeng_desc* d, float t_net, float score_
   if (!make_layout(d, L)) return fail(SDENG_E_INVALID, "bad sizes");
   if (!d->workspace || d->workspace_bytes < L.total * sizeof(float)) return fail(SDENG_E_WORKSPACE, "workspace too small");
   if (d->B == 0) return 0;
-  const int DT = tiles_of(d->d), dpad = 16 * DT;
+  const int DT = tiles_of(d), dpad = 16 * DT;
   float* ws = static_cast<float*>(d->workspace);
   SimArgs a;
   memset(&a, 0, sizeof(a));

@@ -39,11 +39,11 @@ SD_INLINE int feat(int t, int r, int g) { return 16 * t + 4 * g + r; }
 // feat(t, r, g) < d with the lane-dependent part (4g) on one side only: the compare takes a scalar operand,
 // so no per-element index register is ever materialised.
 SD_INLINE bool feat_lt(int t, int r, int g4, int d) { return g4 < d - (16 * t + r); }
-// The same for a kernel with NT feature tiles: NT is the smallest of {1, 2, 4, 8} tiles covering d (sdeng_api.hip tiles_of), so for
-// NT >= 2 we know d > 8 NT and the first NT/2 tiles hold live features only -- no mask instructions there (t is a compile-time
-// constant after unrolling).
+// The same for a kernel with NT feature tiles: NT = ceil(d / 16) exactly (sdeng_api.hip tiles_of), so every tile but the last
+// holds live features only -- no mask instructions there (t is a compile-time constant after unrolling).  (The full-covariance
+// reference kernels may run with one tile more than that; they never use this helper.)
 template <int NT>
-SD_INLINE bool feat_live(int t, int r, int g4, int d) { return (NT >= 2 && 2 * t < NT) ? true : feat_lt(t, r, g4, d); }
+SD_INLINE bool feat_live(int t, int r, int g4, int d) { return (t < NT - 1) ? true : feat_lt(t, r, g4, d); }
 
 // the 4 registers of feature tile t for this lane from a dense vector
 SD_INLINE f32x4 load_tile4(const float* base, int t, int g) { return *reinterpret_cast<const f32x4*>(base + 16 * t + 4 * g); }
@@ -79,7 +79,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // for every compiler-visible VALU writer hipcc emits the `s_nop 2`).  That was the "lanes 48-63, one register"
 // corruption at two waves per SIMD.  Written with builtins the same six instructions come out (the opaque SGPR 1.0
 // keeps fma(a, 1, -hi) from being folded to a subtraction, which would need two separate f16->f32 conversions), and
-// every one of them is visible to the hazard recognizer.  build.py runs the scan on each object as a guard.
+// every one of them is visible to the hazard recognizer (tests/test_build_cpu.py keeps it that way).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 SD_INLINE float opaque_one() {
@@ -109,6 +109,15 @@ SD_INLINE void split8(const f32x4& t0, const f32x4& t1, f16x8& hi, f16x8& lo) {
   lo = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
 }
 
+// odd tile counts: the last K-block holds one live tile, its upper four k-slots are zero
+SD_INLINE void split8_half(const f32x4& t0, f16x8& hi, f16x8& lo) {
+  uint32_t h0, h1, l0, l1;
+  split_pair(t0[0], t0[1], h0, l0);
+  split_pair(t0[2], t0[3], h1, l1);
+  hi = __builtin_bit_cast(f16x8, u32x4{h0, h1, 0u, 0u});
+  lo = __builtin_bit_cast(f16x8, u32x4{l0, l1, 0u, 0u});
+}
+
 // one layer: out[to] = bias[to] (preloaded in `out`) + W in.  The activations are split K-block by K-block right
 // before use, so only 8 packed registers of hi/lo pieces are live at a time.
 template <int NTI, int TO>
@@ -122,7 +131,8 @@ SD_INLINE void dense(const f32x4 (&in)[NTI], f32x4 (&out)[TO], const float* w, i
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     f16x8 xh, xl;
-    split8(in[2 * kb], (2 * kb + 1 < NTI) ? in[2 * kb + 1 < NTI ? 2 * kb + 1 : 0] : zero, xh, xl);
+    if (2 * kb + 1 < NTI) split8(in[2 * kb], in[2 * kb + 1 < NTI ? 2 * kb + 1 : 0], xh, xl);
+    else split8_half(in[2 * kb], xh, xl);
     f16x8 ah[TO], al[TO];
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
@@ -172,9 +182,11 @@ SD_INLINE void fold_lo(f32x4 (&out)[TO], const f32x4 (&mx)[TO]) {
 }
 template <int NT>
 SD_INLINE void split_tiles(const f32x4 (&x)[NT], f16x8 (&xh)[(NT + 1) / 2], f16x8 (&xl)[(NT + 1) / 2]) {
-  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int kb = 0; kb < (NT + 1) / 2; ++kb) split8(x[2 * kb], (2 * kb + 1 < NT) ? x[2 * kb + 1 < NT ? 2 * kb + 1 : 0] : zero, xh[kb], xl[kb]);
+  for (int kb = 0; kb < (NT + 1) / 2; ++kb) {
+    if (2 * kb + 1 < NT) split8(x[2 * kb], x[2 * kb + 1 < NT ? 2 * kb + 1 : 0], xh[kb], xl[kb]);
+    else split8_half(x[2 * kb], xh[kb], xl[kb]);
+  }
 }
 
 // GELU for the step loop: one branch-free piece, 8 fma + exp2 + max + fma (the erf form above costs 2 polynomial

@@ -8,6 +8,8 @@
 // (two cross-lane adds per reduction).  No barrier inside the step loop: the two waves sharing a SIMD interleave
 // freely (matrix and vector issue do not overlap on this part, so instruction count is what is optimised).
 #pragma once
+#include <type_traits>
+
 #include "sim_device.hpp"
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4 };  // GMM: K <= SD_KREG (responsibilities in registers); FULL: full covariances
@@ -66,7 +68,6 @@ template <int NT, int REF, int SC, int FORM, int PAR>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const SimArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int dpad = 16 * NT;
-  constexpr int OT = NT >= 2 ? 2 : 1;  // output tiles produced together: two independent MFMA chains
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,8 +301,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 
       // ---- per pair of output tiles: out_layer (MFMA) -> clip -> cost -> noise -> integrator -> Ito term ----
       float su2 = 0.0f, suz = 0.0f, sux = 0.0f;
-#pragma unroll
-      for (int t0 = 0; t0 < NT; t0 += OT) {
+      // (NT odd: pairs, then the last tile alone -- `t0` is a constant after unrolling, the dead branch goes away)
+      auto out_group = [&](auto otc, int t0) __attribute__((always_inline)) {
+        constexpr int OT = decltype(otc)::value;
         f32x4 u[OT];
         mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
         if (a.clip_model > 0.0f) {
@@ -364,6 +366,11 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
             }
           }
         }
+      };
+#pragma unroll
+      for (int t0 = 0; t0 < NT; t0 += 2) {
+        if (t0 + 1 < NT) out_group(std::integral_constant<int, 2>{}, t0);
+        else out_group(std::integral_constant<int, 1>{}, t0);
       }
       if constexpr (ref_lds) {  // next step's table: every read of this step's copy has been consumed above
         __builtin_amdgcn_sched_barrier(0);
