@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SDENG_ABI_VERSION 2
+#define SDENG_ABI_VERSION 3
 
 /* error codes */
 #define SDENG_OK 0
@@ -109,6 +109,7 @@ typedef struct sdeng_dist {
                            LOGREG: weight_scale, intercept_mean, intercept_scale, threshold;
                            GAUSS_FULL: p0 = sum(log diag L); RINGS: p0 = radial std-dev (d must be 2) */
   float clip;        /* clip applied to the log-density (solver/oc.py:80-87 clip_target); <=0: none */
+  const float* aux;  /* GAUSS_FULL as x0_dist: Cholesky factor L [d,d] (row-major, lower) of the covariance; else NULL */
 } sdeng_dist;
 
 /* ---- drift net: models/mlp.py:99-143 FourierMLP(num_layers=4, channels=64, GELU) wrapped by
@@ -180,6 +181,16 @@ typedef struct sdeng_ref {
  * noise_in == NULL : counter-based Philox4x32-10, counter (particle0+p, feature/4, step, stream), key = seed,
  *                    two Box-Muller pairs on u = ((bits>>9)+0.5)*2^-23; independent of sharding.
  */
+/* ---- initial particles -------------------------------------------------------------------------
+ * x_in != NULL : the caller's x0 [B,d] (e.g. prior.sample((B,)) as solver/oc.py:132 does).
+ * x_in == NULL : x0 is drawn by the engine from `x0_dist`, z = the Philox normals of stream 1 at step 0 (same counter layout as
+ *                the step noise, so x0 of global particle p does not depend on the sharding):
+ *     ISO_GAUSS   x0 = p0 + p1 * z                IsotropicGauss.sample   distr/gauss.py:772-787 (no truncation)
+ *     GAUSS_DIAG  x0 = loc + scale * z            Gauss.sample distr/gauss.py:235-239;  scale == NULL: x0 = loc  (Delta.sample, distr/delta.py:27-31)
+ *     GAUSS_FULL  x0 = loc + L z  (L = aux)       GaussFull.sample        distr/gauss.py:709-713 (MultivariateNormal)
+ *   ISO_GAUSS / GAUSS_DIAG without FLAG_INIT_LOGP are drawn in registers by the step-loop kernel itself (x0 never touches HBM);
+ *   otherwise x0 is first materialised in the workspace.  x0_out (optional, [B,d]) receives the drawn x0 either way.
+ */
 typedef struct sdeng_desc {
   int32_t abi_version;   /* SDENG_ABI_VERSION                                              */
   int32_t form;          /* SDENG_FORM_*                                                   */
@@ -188,7 +199,7 @@ typedef struct sdeng_desc {
   int64_t particle0;     /* global index of this shard's first particle (Philox counter)   */
   uint64_t seed;         /* Philox key                                                     */
   const float* coef;     /* [N][SDENG_NCOEF], device                                        */
-  const float* x_in;     /* [B,d]                                                           */
+  const float* x_in;     /* [B,d], or NULL: draw x0 from x0_dist                             */
   float* x_out;          /* [B,d]                                                           */
   float* rnd_out;        /* [B]  (the reference's rnd[B,1])                                 */
   float* xs_out;         /* optional trajectory [N+1,B,d] (return_traj=True), or NULL       */
@@ -204,6 +215,8 @@ typedef struct sdeng_desc {
   size_t workspace_bytes;
   void* ev_start;        /* optional hipEvent_t recorded on `stream` right before the step-loop kernel */
   void* ev_stop;         /* optional hipEvent_t recorded right after it (roofline timing)            */
+  sdeng_dist x0_dist;    /* distribution of x0 when x_in == NULL (see above)                 */
+  float* x0_out;         /* optional [B,d]: the x0 that was drawn                             */
 } sdeng_desc;
 
 /* Version of this ABI compiled into the library. */
@@ -245,6 +258,11 @@ int sdeng_philox_normal(uint64_t seed, int32_t step, int64_t particle0, int32_t 
 /* The same for n_steps consecutive steps in one launch: out[n_steps,B,d] (the noise a training call keeps, losses/oc.py:277, :537). */
 int sdeng_philox_normal_steps(uint64_t seed, int32_t step0, int32_t n_steps, int64_t particle0, int32_t B, int32_t d,
                               uint32_t stream_id, float* out, void* stream);
+
+/* prior.sample((B,)) on the device, out[B,d]: exactly the x0 that sdeng_simulate draws for x_in == NULL with the same
+ * (dist, seed, particle0).  Replaces IsotropicGauss.sample / Gauss.sample / Delta.sample / GaussFull.sample (distr/gauss.py:772-787,
+ * 235-239, 709-713; distr/delta.py:27-31). */
+int sdeng_sample_x0(const sdeng_dist* dist, uint64_t seed, int64_t particle0, int32_t B, int32_t d, float* out, void* stream);
 
 #ifdef __cplusplus
 }

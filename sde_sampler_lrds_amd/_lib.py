@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NCOEF = 16
 
 FORM_LIN, FORM_EM, FORM_CMCD, FORM_EUBO, FORM_CMCD_EUBO = 0, 1, 2, 3, 4
@@ -24,7 +24,7 @@ _fp = C.c_void_p  # device pointers travel as integers
 
 class Dist(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("loc", _fp), ("scale", _fp), ("w", _fp),
-                ("p0", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("p3", C.c_float), ("clip", C.c_float)]
+                ("p0", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("p3", C.c_float), ("clip", C.c_float), ("aux", _fp)]
 
 
 class TimeEmbed(C.Structure):
@@ -50,7 +50,7 @@ class Desc(C.Structure):
                 ("coef", _fp), ("x_in", _fp), ("x_out", _fp), ("rnd_out", _fp), ("xs_out", _fp), ("noise_in", _fp),
                 ("net", Net), ("ref", Ref), ("target", Dist), ("ref_dist", Dist), ("prior", Dist),
                 ("cmcd_g", C.c_float), ("cmcd_clip", C.c_float), ("workspace", _fp), ("workspace_bytes", C.c_size_t),
-                ("ev_start", _fp), ("ev_stop", _fp)]
+                ("ev_start", _fp), ("ev_stop", _fp), ("x0_dist", Dist), ("x0_out", _fp)]
 
 
 class EngineError(RuntimeError):
@@ -64,7 +64,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsdeng.so
 
 EXPORTS = ["sdeng_abi_version", "sdeng_last_error", "sdeng_workspace_bytes", "sdeng_simulate", "sdeng_logz",
            "sdeng_logz_workspace_bytes", "sdeng_ctrl_forward", "sdeng_dist_eval", "sdeng_dist_workspace_bytes",
-           "sdeng_philox_normal", "sdeng_philox_normal_steps"]
+           "sdeng_philox_normal", "sdeng_philox_normal_steps", "sdeng_sample_x0"]
 
 
 def lib() -> C.CDLL:
@@ -95,6 +95,8 @@ def lib() -> C.CDLL:
     L.sdeng_philox_normal.argtypes = [C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.sdeng_philox_normal_steps.restype = C.c_int
     L.sdeng_philox_normal_steps.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.sdeng_sample_x0.restype = C.c_int
+    L.sdeng_sample_x0.argtypes = [C.POINTER(Dist), C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     if L.sdeng_abi_version() != ABI_VERSION:
         raise ImportError(f"libsdeng.so ABI {L.sdeng_abi_version()} != binding ABI {ABI_VERSION}")
     _LIB = L

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     const bool live = row < static_cast<uint32_t>(s.B);
     const uint32_t pidx = static_cast<uint32_t>(s.particle0 + row);
     f32x4 x[NT];
-    load_rows<NT>(s.x_in, row, s.d, live, g, x);
+    initial_state<NT>(s, row, pidx, live, g, trash, x);
     float rnd = 0.0f;
     if (s.rnd_init) rnd = (live ? s.rnd_init[row] : 0.0f);  // rnd0 = log p_prior(x0)  (losses/oc.py:695-699)
     if (s.xs_out) store_rows<NT>(s.xs_out, trash, row, s.d, live, g, x);

@@ -590,6 +590,52 @@ __global__ void k_philox(unsigned seed_lo, unsigned seed_hi, int step, long long
     if (4 * jb + e < d) o[static_cast<size_t>(row) * d + 4 * jb + e] = z[e];
 }
 
+// ------------------------------------------------------------------------------------------------
+// prior.sample((B,)) on the device: the x0 the step-loop kernels draw in registers, materialised.
+//   ISO_GAUSS / GAUSS_DIAG: one thread per (particle, quad of features), x0_quad() of sim_device.hpp;
+//   GAUSS_FULL (GaussFull.sample, distr/gauss.py:709-713: MultivariateNormal = loc + L z): 16 particles per block, their
+//   normals staged in LDS, then x0_i = loc_i + sum_{j <= i} L[i][j] z_j.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sample_x0(X0Dev q, unsigned seed_lo, unsigned seed_hi, long long particle0, int B, int d, float* out) {
+  const int nj = (d + 3) / 4;
+  const long long idx = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  if (idx >= static_cast<long long>(B) * nj) return;
+  const int row = static_cast<int>(idx / nj), jb = static_cast<int>(idx % nj);
+  const f32x4 x = x0_quad(q, static_cast<uint32_t>(particle0 + row), jb, d, seed_lo, seed_hi);
+  for (int e = 0; e < 4; ++e)
+    if (4 * jb + e < d) out[static_cast<size_t>(row) * d + 4 * jb + e] = x[e];
+}
+__global__ void __launch_bounds__(256) k_sample_x0_full(const float* loc, const float* L, unsigned seed_lo, unsigned seed_hi, long long particle0,
+                                                       int B, int d, float* out) {
+  __shared__ float z[16][132];
+  const int row0 = blockIdx.x * 16, nj = (d + 3) / 4;
+  for (int i = threadIdx.x; i < 16 * nj; i += 256) {
+    const int r = i / nj, jb = i % nj;
+    const f32x4 v = philox_normal4(static_cast<uint32_t>(particle0 + row0 + r), 0u, static_cast<uint32_t>(jb), SD_X0_STREAM, seed_lo, seed_hi);
+    for (int e = 0; e < 4; ++e) z[r][4 * jb + e] = v[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16 * d; i += 256) {
+    const int r = i / d, f = i % d;
+    if (row0 + r >= B) continue;
+    const float* Lf = L + static_cast<size_t>(f) * d;
+    float acc = 0.0f;
+    for (int j = 0; j <= f; ++j) acc = __builtin_fmaf(Lf[j], z[r][j], acc);
+    out[static_cast<size_t>(row0 + r) * d + f] = loc[f] + acc;
+  }
+}
+int sd_launch_sample_x0(const sdeng_dist& ds, unsigned lo, unsigned hi, long long p0, int B, int d, float* out, hipStream_t s) {
+  if (ds.kind == SDENG_DIST_GAUSS_FULL) {
+    hipLaunchKernelGGL(k_sample_x0_full, dim3((B + 15) / 16), dim3(256), 0, s, ds.loc, ds.aux, lo, hi, p0, B, d, out);
+  } else {
+    X0Dev q;
+    q.kind = ds.kind; q.loc = ds.loc; q.scale = ds.scale; q.p0 = ds.p0; q.p1 = ds.p1; q.out = nullptr;
+    const long long n = static_cast<long long>(B) * ((d + 3) / 4);
+    hipLaunchKernelGGL(k_sample_x0, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, q, lo, hi, p0, B, d, out);
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
 // ---- host-side launch wrappers -------------------------------------------------------------------
 int sd_launch_pack(const PackArgs& a, hipStream_t s) {
   const int total = sd_lds_weight_floats(a.NT) * 2 + 3 * 64 + 16 * a.NT;

@@ -72,3 +72,4 @@ int sd_launch_dist_eval(const DistEvalArgs& a, hipStream_t s);
 int sd_launch_terminal(const TerminalArgs& a, hipStream_t s);
 int sd_launch_logz(const float* rnd, long long B, float* stats, float* weights, float* scratch, hipStream_t s);
 int sd_launch_philox(unsigned lo, unsigned hi, int step, int n_steps, long long p0, int B, int d, unsigned stream_id, float* out, hipStream_t s);
+int sd_launch_sample_x0(const sdeng_dist& ds, unsigned lo, unsigned hi, long long p0, int B, int d, float* out, hipStream_t s);

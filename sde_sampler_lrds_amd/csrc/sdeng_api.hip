@@ -103,8 +103,15 @@ static size_t dist_floats(const sdeng_dist& ds, int dpad) {
   return 0;
 }
 
+// x_in == NULL: is x0 written to memory before the step loop (workspace or x0_out), or drawn in registers by the kernel?
+// In registers for ISO_GAUSS / GAUSS_DIAG unless the initial log-density is needed (it is evaluated from x0 in memory).
+static bool x0_materialised(const sdeng_desc* d) {
+  return d->x0_dist.kind == SDENG_DIST_GAUSS_FULL || (d->flags & SDENG_FLAG_INIT_LOGP) || d->form == SDENG_FORM_CMCD;
+}
+static int check_x0_dist(const sdeng_desc* d);
+
 struct Layout {
-  size_t wpack, temb, stheta, ref_tab, ref_mean, ref_consts, target, ref_dist, prior, rnd_init, trash, logz, cmcd, total;
+  size_t wpack, temb, stheta, ref_tab, ref_mean, ref_consts, target, ref_dist, prior, rnd_init, trash, logz, cmcd, x0, total;
 };
 
 static bool make_layout(const sdeng_desc* d, Layout& L) {
@@ -137,6 +144,8 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
     o += align64(sd_lr_floats(DT, n)) + align64(32 * sd_lr_row_kb(n));
     if (d->form == SDENG_FORM_CMCD || d->form == SDENG_FORM_CMCD_EUBO) o += align64(DT * sd_kb(DT) * 512) + align64(16 * DT);
   }
+  L.x0 = o;
+  if (!d->x_in && x0_materialised(d)) o += align64(static_cast<size_t>(d->B) * d->d);
   L.total = o;
   return true;
 }
@@ -390,7 +399,11 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   Layout L;
   if (!make_layout(d, L)) return fail(SDENG_E_INVALID, "bad sizes: B=%d d=%d N=%d (need 1 <= d <= 128)", d->B, d->d, d->N);
   if (d->B == 0) return 0;
-  if ((!d->coef && d->N > 0) || !d->x_in || !d->x_out || !d->rnd_out) return fail(SDENG_E_INVALID, "null coef/x_in/x_out/rnd_out");
+  if ((!d->coef && d->N > 0) || !d->x_out || !d->rnd_out) return fail(SDENG_E_INVALID, "null coef/x_out/rnd_out");
+  if (!d->x_in) {
+    int rcx = check_x0_dist(d);
+    if (rcx) return rcx;
+  }
   if (!d->workspace || d->workspace_bytes < L.total * sizeof(float))
     return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, L.total * sizeof(float));
   if (static_cast<long long>(d->B) * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "B*d >= 2^31");
@@ -411,6 +424,18 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   a.xs_out = d->xs_out; a.noise_in = d->noise_in;
   a.trash = ws + L.trash;
   a.ntiles = (d->B + 15) / 16;
+  sdeng_desc dm;  // x0 drawn by the engine and needed in memory: materialise it, then run as if the caller had passed it
+  if (!d->x_in && x0_materialised(d)) {
+    float* x0 = d->x0_out ? d->x0_out : ws + L.x0;
+    SD_HIP(sd_launch_sample_x0(d->x0_dist, a.seed_lo, a.seed_hi, d->particle0, d->B, d->d, x0, s));
+    dm = *d;
+    dm.x_in = x0;
+    d = &dm;
+    a.x_in = x0;
+  } else if (!d->x_in) {
+    a.x0.kind = d->x0_dist.kind; a.x0.loc = d->x0_dist.loc; a.x0.scale = d->x0_dist.scale;
+    a.x0.p0 = d->x0_dist.p0; a.x0.p1 = d->x0_dist.p1; a.x0.out = d->x0_out;
+  }
 
   if (d->form == SDENG_FORM_CMCD || d->form == SDENG_FORM_CMCD_EUBO) return simulate_cmcd(d, L, ws, DT, a, s);
   if (d->net.ctrl_kind == SDENG_CTRL_NONE) return simulate_euler(d, L, ws, DT, a, s);
@@ -547,6 +572,29 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     tp.B = d->B; tp.d = d->d; tp.dpad = dpad; tp.x = d->x_out; tp.rnd = d->rnd_out;
     SD_HIP(sd_launch_terminal(tp, s));
   }
+  return 0;
+}
+
+static int check_x0_dist(const sdeng_desc* d) {
+  const sdeng_dist& q = d->x0_dist;
+  if (d->form == SDENG_FORM_EUBO || d->form == SDENG_FORM_CMCD_EUBO)
+    return fail(SDENG_E_INVALID, "the noising loops start from samples of the TARGET: x_in is required");
+  if (q.kind == SDENG_DIST_ISO_GAUSS) return 0;
+  if (q.kind == SDENG_DIST_GAUSS_DIAG) return q.loc ? 0 : fail(SDENG_E_INVALID, "x0_dist GAUSS_DIAG needs loc (scale may be NULL: x0 = loc)");
+  if (q.kind == SDENG_DIST_GAUSS_FULL) return (q.loc && q.aux) ? 0 : fail(SDENG_E_INVALID, "x0_dist GAUSS_FULL needs loc and the Cholesky factor (aux)");
+  return fail(SDENG_E_UNSUPPORTED, "x_in == NULL: no sampler for x0_dist kind %d (ISO_GAUSS, GAUSS_DIAG, GAUSS_FULL)", q.kind);
+}
+
+extern "C" int sdeng_sample_x0(const sdeng_dist* dist, uint64_t seed, int64_t particle0, int32_t B, int32_t d, float* out, void* stream) {
+  if (!dist || !out || B < 0 || d < 1 || d > 128) return fail(SDENG_E_INVALID, "bad argument");
+  if (B == 0) return 0;
+  sdeng_desc tmp;
+  memset(&tmp, 0, sizeof(tmp));
+  tmp.x0_dist = *dist;
+  int rc = check_x0_dist(&tmp);
+  if (rc) return rc;
+  SD_HIP(sd_launch_sample_x0(*dist, static_cast<unsigned>(seed & 0xFFFFFFFFull), static_cast<unsigned>(seed >> 32), particle0, B, d, out,
+                             static_cast<hipStream_t>(stream)));
   return 0;
 }
 

@@ -388,6 +388,37 @@ SD_INLINE f32x4 philox_normal4(uint32_t pidx, uint32_t step, uint32_t jb, uint32
 }
 
 // ----------------------------------------------------------------------------------------------
+// Initial particles: prior.sample((B,)) as a pure function of (seed, global particle, feature) -- the Philox
+// normals of stream 1 at step 0.  IsotropicGauss.sample (distr/gauss.py:777): loc + scale * randn; Gauss.sample: loc + scale * z per
+// feature; Delta.sample (distr/delta.py:31): loc.  One quad = features 4 jb .. 4 jb + 3 of one particle; pads are 0.
+// The same function serves the in-register draw of the step-loop kernels and the standalone sampler (k_sample_x0).
+// ----------------------------------------------------------------------------------------------
+#define SD_X0_STREAM 1u
+SD_INLINE f32x4 x0_quad(const X0Dev& q, uint32_t pidx, int jb, int d, uint32_t k0, uint32_t k1) {
+  f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (q.kind == SDENG_DIST_GAUSS_DIAG && q.scale == nullptr) {  // Delta: no draw
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = (4 * jb + r < d) ? q.loc[4 * jb + r] : 0.0f;
+    return x;
+  }
+  const f32x4 z = philox_normal4(pidx, 0u, static_cast<uint32_t>(jb), SD_X0_STREAM, k0, k1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * jb + r;
+    float v;
+    if (q.kind == SDENG_DIST_ISO_GAUSS) v = q.p0 + q.p1 * z[r];
+    else v = (f < d) ? q.loc[f] + q.scale[f] * z[r] : 0.0f;
+    x[r] = (f < d) ? v : 0.0f;
+  }
+  return x;
+}
+template <int NT>
+SD_INLINE void draw_x0(const SimArgs& a, uint32_t pidx, int g, f32x4 (&x)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) x[t] = x0_quad(a.x0, pidx, 4 * t + g, a.d, a.seed_lo, a.seed_hi);
+}
+
+// ----------------------------------------------------------------------------------------------
 // Gaussian-mixture score (distr/gauss.py:97-107 score_mog).
 // tab: [K][2][dpad] (mean, 1/var); consts: [K][cstride] with [0] = 0.5*sum log var, [1] = log w_k.
 // ----------------------------------------------------------------------------------------------
@@ -681,6 +712,16 @@ SD_INLINE void store_rows(float* __restrict__ dst, float* __restrict__ trash, ui
                           const f32x4 (&v)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) store_quad(dst, trash, row, d, live, t, g, v[t]);
+}
+// x0 of a tile: read from x_in, or drawn in registers (and optionally written to x0_out)
+template <int NT>
+SD_INLINE void initial_state(const SimArgs& a, uint32_t row, uint32_t pidx, bool live, int g, float* trash, f32x4 (&x)[NT]) {
+  if (a.x0.kind == SDENG_DIST_NONE) {
+    load_rows<NT>(a.x_in, row, a.d, live, g, x);
+  } else {
+    draw_x0<NT>(a, pidx, g, x);
+    if (a.x0.out) store_rows<NT>(a.x0.out, trash, row, a.d, live, g, x);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------

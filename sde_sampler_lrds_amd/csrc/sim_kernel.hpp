@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     const bool live = row < static_cast<uint32_t>(a.B);
     const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
     f32x4 x[NT];
-    load_rows<NT>(a.x_in, row, a.d, live, g, x);
+    initial_state<NT>(a, row, pidx, live, g, trash, x);
     // rnd0 = log p_prior(x0) when the loss asks for it (losses/oc.py:695-699, 935-939), from k_dist_eval
     float rnd = 0.0f;
     if (a.rnd_init) rnd = (live ? a.rnd_init[row] : 0.0f);

@@ -86,13 +86,14 @@ def dist_desc(obj, device, keep, clip=None) -> L.Dist:
         hit = getattr(obj, "_sdeng_chol", None)
         if hit is None or hit[0] != key:  # Cholesky factor, its inverse and log-determinant once per parameter version
             tril = torch.linalg.cholesky(obj.cov.detach().float().cpu())
-            hit = (key, torch.linalg.inv(tril).to(device), float(tril.diagonal().log().sum()))
+            hit = (key, torch.linalg.inv(tril).to(device), float(tril.diagonal().log().sum()), tril.to(device))
             obj._sdeng_chol = hit
         ds.kind = L.DIST_GAUSS_FULL
         ds.loc = _dev_f32(obj.loc, device, keep)
         ds.scale = _dev_f32(obj.prec, device, keep)
         ds.w = _dev_f32(hit[1], device, keep)
         ds.p0 = hit[2]
+        ds.aux = _dev_f32(hit[3], device, keep)  # L itself: GaussFull.sample (x0_dist)
         return ds
     if n in ("LogisticRegression", "SyntheticLogReg"):
         ds.kind = L.DIST_LOGREG
@@ -112,6 +113,43 @@ def dist_desc(obj, device, keep, clip=None) -> L.Dist:
         ds.p0 = float(obj.radius_dist.component_distribution.scale.reshape(-1)[0])
         return ds
     raise UnsupportedByEngine(f"no HIP log-density/score for distribution {n}")
+
+
+class InitialDraw:
+    """``prior.sample((B,))`` left to the engine: pass it wherever a loss takes ``x`` and the kernel draws
+    x0 = loc + scale * z itself (z = Philox stream 1 at step 0, keyed by the loss's seed and the global particle index), in
+    registers for IsotropicGauss / Gauss / Delta priors -- x0 never exists in HBM.  ``tensor(seed, particle0)`` gives the same
+    x0 as a device tensor (``sdeng_sample_x0``), for callers that need it.  Reference: IsotropicGauss.sample distr/gauss.py:772-787,
+    Delta.sample distr/delta.py:27-31, GaussFull.sample distr/gauss.py:709-713 (all on torch's global generator upstream)."""
+
+    def __init__(self, prior, batch_size: int, device=None):
+        if _name(prior) == "IsotropicGauss" and getattr(prior, "truncate_quartile", None) is not None:
+            raise UnsupportedByEngine("truncated IsotropicGauss prior: no native sampler")
+        self.prior, self.batch_size = prior, int(batch_size)
+        self.device = torch.device(device) if device is not None else next(iter(prior.buffers())).device
+        self.shape = (self.batch_size, int(prior.dim))
+        self.is_cuda = self.device.type == "cuda"
+
+    def desc(self, keep) -> L.Dist:
+        ds = dist_desc(self.prior, self.device, keep)
+        if _name(self.prior) == "Delta":
+            ds.scale = None  # Delta.sample repeats loc (its tiny scale only enters the log-density)
+        if ds.kind not in (L.DIST_ISO_GAUSS, L.DIST_GAUSS_DIAG, L.DIST_GAUSS_FULL):
+            raise UnsupportedByEngine(f"no native sampler for prior {_name(self.prior)}")
+        return ds
+
+    def tensor(self, seed: int, particle0: int = 0) -> torch.Tensor:
+        keep = []
+        ds = self.desc(keep)
+        B, d = self.shape
+        out = torch.empty(B, d, dtype=torch.float32, device=self.device)
+        L.check(L.lib().sdeng_sample_x0(C.byref(ds), int(seed), int(particle0), B, d, out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+
+def sample_prior(prior, batch_size: int, seed: int, particle0: int = 0, device=None) -> torch.Tensor:
+    """prior.sample((B,)) from the engine's counter-based stream: a pure function of (seed, global particle index)."""
+    return InitialDraw(prior, batch_size, device).tensor(seed, particle0)
 
 
 def resolve_logp(fn):
@@ -437,14 +475,20 @@ def run(desc: L.Desc, x: torch.Tensor, keep: list, return_traj=False, noise=None
     lib = L.lib()
     device = x.device
     B, d, N = x.shape[0], x.shape[1], desc.N
-    xin = x.detach().to(torch.float32).contiguous()
-    keep.append(xin)
-    x_out = torch.empty_like(xin)
+    if isinstance(x, InitialDraw):  # x0 drawn by the engine: no input array
+        desc.x_in = None
+        desc.x0_dist = x.desc(keep)
+        x_out = torch.empty(B, d, dtype=torch.float32, device=device)
+    else:
+        xin = x.detach().to(torch.float32).contiguous()
+        keep.append(xin)
+        desc.x_in = xin.data_ptr()
+        x_out = torch.empty_like(xin)
     rnd = torch.empty(B, 1, dtype=torch.float32, device=device)
     xs = torch.empty(N + 1, B, d, dtype=torch.float32, device=device) if return_traj else None
     desc.abi_version = L.ABI_VERSION
     desc.B, desc.d = B, d
-    desc.x_in, desc.x_out, desc.rnd_out = xin.data_ptr(), x_out.data_ptr(), rnd.data_ptr()
+    desc.x_out, desc.rnd_out = x_out.data_ptr(), rnd.data_ptr()
     desc.xs_out = xs.data_ptr() if return_traj else None
     if noise is not None:
         nz = noise.detach().to(device=device, dtype=torch.float32).contiguous()

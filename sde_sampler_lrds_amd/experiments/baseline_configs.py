@@ -109,3 +109,19 @@ def build_cmcd_logreg(device, B, N, seed=4):
     info = dict(target=target, prior=prior, ctrl=ctrl, X=X, y=y, mean=mean, cov=cov, d=d, flops=_flops(d),
                 workload="LogisticRegression d=61 (sonar-shaped synthetic data), CMCD, GaussFull prior")
     return loss, ts, x0, (target.unnorm_log_prob,), dict(initial_log_prob=prior.log_prob, train=False), info
+
+
+BUILDERS = {"rds_gmm": build_rds_gmm, "pis_phi4": build_pis_phi4, "cmcd_logreg": build_cmcd_logreg}
+FULL_SIZE = {"rds_gmm": (65536, 256), "pis_phi4": (131072, 512), "cmcd_logreg": (65536, 256)}  # BASELINE.json (cfg 4: one GPU's shard of 262 144)
+
+
+def prior_of(cfg, info, device):
+    """The prior the reference's solver samples x0 from for this workload (solver/oc.py:132): IsotropicGauss(scale 1) for the VP
+    RDS solver (conf/solver/vp_rds.yaml), Delta for PIS (conf/solver/pis.yaml), the GaussFull of CMCD.update_prior (solver/oc.py:291-303)."""
+    from ..distr.delta import Delta
+    from ..distr.gauss import IsotropicGauss
+    if cfg == "rds_gmm":
+        return IsotropicGauss(dim=info["d"], scale=1.0).to(device)
+    if cfg == "pis_phi4":
+        return Delta(dim=info["d"]).to(device)
+    return info["prior"]

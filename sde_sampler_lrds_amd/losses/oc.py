@@ -152,6 +152,7 @@ class BaseOCLoss:
                                         "(log-variance training is: method='lv')")
         if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
             raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built")
+        x = self._x0(x)
         if self.traj_per_sample != 1:
             x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
         N, (B, d) = ts.numel() - 1, x.shape
@@ -190,6 +191,11 @@ class BaseOCLoss:
 
     def _ctrl(self, use_ema):
         return self.generative_ctrl_ema if use_ema else self.generative_ctrl
+
+    def _x0(self, x):
+        """``x`` as a tensor: an ``engine.InitialDraw`` (x0 left to the engine) is materialised with this loss's seed and shard
+        offset -- the same x0 the kernel would have drawn in registers."""
+        return x.tensor(self.seed, self.particle0) if isinstance(x, E.InitialDraw) else x
 
     def _sde_cpu(self):
         if self._cpu_sde is None:
@@ -259,6 +265,8 @@ class BaseOCLoss:
     def _simulate(self, ts, x, *, terminal_unnorm_log_prob, reference_log_prob=None, initial_log_prob=None, form,
                   flags, use_ema, return_traj, noise, ref=("none", {}), coef_kw=None):
         E.require_gpu(x)
+        if isinstance(x, E.InitialDraw) and (form == L.FORM_EUBO or (initial_log_prob is not None and E.resolve_logp(initial_log_prob) is None)):
+            x = self._x0(x)  # an opaque initial log-density needs x0 as a tensor; the noising loops start from data anyway
         device = x.device
         keep = []
         desc = L.Desc()
@@ -408,6 +416,8 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
             raise E.UnsupportedByEngine("ControlledLangevinSDELoss(use_rescaling=False) scales the control twice upstream "
                                         "(losses/oc.py:716-719); not reproduced")
         E.require_gpu(x)
+        if eubo:
+            x = self._x0(x)
         device = x.device
         keep = []
         desc = L.Desc()
@@ -456,6 +466,7 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
             raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
         if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
             raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control: not built")
+        x = self._x0(x)
         if self.traj_per_sample != 1:
             x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
         N, (B, d) = ts.numel() - 1, x.shape

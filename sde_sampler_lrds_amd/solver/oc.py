@@ -128,9 +128,23 @@ class TrainableDiff:
     def clipped_target_unnorm_log_prob(self, x):
         return clip_and_log(self.target.unnorm_log_prob(x), max_norm=self.clip_target, name="target")
 
+    def sample_prior(self, batch_size):
+        """``self.prior.sample((batch_size,))`` of solver/oc.py:120,132.  ``native_prior`` (default on): x0 is left to the engine
+         -- a pure function of (loss.seed, global particle index), drawn inside the step-loop kernel, so "identical seeds"
+        covers x0 too and a sharded run draws the same particles as a single-GPU one.  Off: torch's global generator, like upstream."""
+        from .. import engine as E
+        if self.cfg.get("native_prior", True) and self.device.type == "cuda":
+            try:
+                draw = E.InitialDraw(self.prior, batch_size, self.device)
+                draw.desc([])
+                return draw
+            except E.UnsupportedByEngine:
+                pass
+        return self.prior.sample((batch_size,)).to(self.device)
+
     def compute_results(self, use_ema=True) -> Results:
         """solver/oc.py:129-160: one pass with trajectories + weights, one timed pass without."""
-        x = self.prior.sample((self.eval_batch_size,)).to(self.device)
+        x = self.sample_prior(self.eval_batch_size)
         if self.eval_ts is None:
             self.eval_ts = self.eval_timesteps(device=self.device) if self._plain_grid() else self.eval_timesteps().to(self.device)
         ts = self.eval_ts

@@ -12,6 +12,7 @@ import math
 import pytest
 import torch
 
+from oracle import baseline_oracles as bo
 from oracle import sde_oracle as orc
 from sde_sampler_lrds_amd import engine as E
 from sde_sampler_lrds_amd import parallel
@@ -55,13 +56,21 @@ def _check_estimators(rnd):
     assert abs(float(weights.double().sum()) - 1.0) < 1e-4
 
 
-def _tol(x_err, rnd_err, name):
-    print(f"{name}: block [{P0},{P0 + PB}) vs oracle: x_N {x_err:.2e}, rnd {rnd_err:.2e}")
-    assert x_err < 2e-4 and rnd_err < 2e-4
-
-
-def _rnd_err(rnd, ref, scale):
-    return float((rnd.cpu().flatten() - ref.flatten()).abs().max()) / scale
+def _block_vs_oracle(cfg, info, ts, x0, x, rnd, seed, name, p0=P0, pb=PB):
+    """A block of the full-size run against the oracle on just those particles with the same counter-based noise ('identical seeds'
+    mode).  Tolerance: 1e-5 (the north_star's bound), or 10 x what the block itself moves when every normal is perturbed by the
+    kernel's Box-Muller error (1.2e-6), whichever is larger -- measured here, printed with the achieved error."""
+    run = bo.runner(cfg, info, ts)
+    xb = x0[p0:p0 + pb].cpu()
+    base = orc.PhiloxNoise(seed, particle0=p0)
+    ox, ornd, scale = run(xb, base)
+    px, prnd, _ = run(xb, bo.PerturbedNoise(base))
+    sens = max(gc.rel_err(px, ox), float((prnd - ornd).abs().max()) / scale)
+    x_err = gc.rel_err(x[p0:p0 + pb].cpu(), ox)
+    r_err = float((rnd[p0:p0 + pb].cpu().flatten() - ornd.flatten()).abs().max()) / scale
+    tol = max(1e-5, 10 * sens)
+    print(f"{name}: block [{p0},{p0 + pb}) vs oracle: x_N {x_err:.2e}, rnd {r_err:.2e}  (tolerance {tol:.1e}; noise sensitivity {sens:.1e})")
+    assert x_err < tol and r_err < tol
 
 
 @pytest.mark.gpu
@@ -71,17 +80,7 @@ def test_cfg2_rds_gmm_65536x256(gpu):
     loss.seed = 5
     x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
     _check_estimators(rnd)
-    sde = orc.VP(0.1, 10.0, 1.0, 1.0)
-    tgt = orc.GMMDiag(info["target"].loc.cpu(), info["target"].scale.cpu(), info["target"].mixture_weights.cpu())
-    ctrl = orc.Ctrl(_sd(info["ctrl"]), "clipped", clip_model=1e4)
-    means, var, w = info["means"].cpu(), 0.5 * torch.ones(info["K"], info["d"]), torch.ones(info["K"])
-    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
-    refd = orc.GMMDiag(loc0, v0.sqrt(), w)
-    with torch.no_grad():
-        ox, ornd, _ = orc.simulate_ei_ref(ts.cpu(), x0[P0:P0 + PB].cpu(), ctrl, sde, tgt.logp, refd.logp,
-                                          lambda t, xx: orc.mog_score(xx, w, *sde.marginal_diag(t, means, var)),
-                                          orc.PhiloxNoise(5, particle0=P0))
-    _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(tgt.logp(ox).abs().max()))), "cfg2")
+    _block_vs_oracle("rds_gmm", info, ts, x0, x, rnd, 5, "cfg2")
 
 
 @pytest.mark.gpu
@@ -91,15 +90,7 @@ def test_cfg3_pis_phi4_131072x512(gpu):
     loss.seed = 6
     x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
     _check_estimators(rnd)
-    g, T = math.sqrt(0.2), 5.0
-    sde = orc.ScaledBM(g, T)
-    tgt = orc.PhiFour(0.1, 0.0, info["d"], 20.0)
-    ctrl = orc.Ctrl(_sd(info["ctrl"]), "score", clip_model=1e4, target_score=tgt.score, clip_score=1e4, scale_score=1.0)
-    refd = orc.GaussDiag(torch.zeros(info["d"]), torch.full((info["d"],), g * math.sqrt(T)))
-    with torch.no_grad():
-        ox, ornd, _ = orc.simulate_em_ref(ts.cpu(), x0[P0:P0 + PB].cpu(), ctrl, sde, tgt.logp, refd.logp, None,
-                                          orc.PhiloxNoise(6, particle0=P0))
-    _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(ornd.abs().max()))), "cfg3")
+    _block_vs_oracle("pis_phi4", info, ts, x0, x, rnd, 6, "cfg3")
 
 
 @pytest.mark.gpu
@@ -109,13 +100,7 @@ def test_cfg4_cmcd_logreg_shard_65536x256(gpu):
     loss.seed = 7
     x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
     _check_estimators(rnd)
-    tgt = orc.LogReg(info["X"], info["y"], 4.5, -2.5, 0.5)
-    prior = orc.GaussFull(info["mean"], info["cov"])
-    ctrl = orc.Ctrl(_sd(info["ctrl"]), "score", clip_model=1e4, target_score=tgt.score, clip_score=1e4, scale_score=1.0)
-    with torch.no_grad():
-        ox, ornd, _ = orc.simulate_cmcd(ts.cpu(), x0[P0:P0 + PB].cpu(), ctrl, tgt.score, prior.score, 1.0, 1.0, 1e5, tgt.logp,
-                                        prior.logp, orc.PhiloxNoise(7, particle0=P0))
-    _tol(gc.rel_err(x[P0:P0 + PB].cpu(), ox), _rnd_err(rnd[P0:P0 + PB], ornd, max(1.0, float(ornd.abs().max()))), "cfg4")
+    _block_vs_oracle("cmcd_logreg", info, ts, x0, x, rnd, 7, "cfg4")
 
 
 @pytest.mark.gpu
@@ -129,17 +114,8 @@ def test_pis_phi4_pad_boundaries(gpu, d):
     loss, ts, x0, args, kw, info = cfgs.build_pis_phi4(gpu, B, N, d=d)
     loss.seed = 3
     x, rnd, _ = loss.simulate(ts, x0, *args, **kw)
-    g, T = math.sqrt(0.2), 5.0
-    sde = orc.ScaledBM(g, T)
-    tgt = orc.PhiFour(0.1, 0.0, d, 20.0)
-    ctrl = orc.Ctrl(_sd(info["ctrl"]), "score", clip_model=1e4, target_score=tgt.score, clip_score=1e4, scale_score=1.0)
-    refd = orc.GaussDiag(torch.zeros(d), torch.full((d,), g * math.sqrt(T)))
-    with torch.no_grad():
-        ox, ornd, _ = orc.simulate_em_ref(ts.cpu(), x0[:64].cpu(), ctrl, sde, tgt.logp, refd.logp, None, orc.PhiloxNoise(3))
-    x_err = gc.rel_err(x[:64].cpu(), ox)
-    r_err = _rnd_err(rnd[:64], ornd, max(1.0, float(ornd.abs().max())))
-    print(f"pis phi4 d={d}: x_N {x_err:.2e}, rnd {r_err:.2e}")
-    assert x_err < 2e-4 and r_err < 2e-4 and bool(torch.isfinite(rnd).all())
+    _block_vs_oracle("pis_phi4", info, ts, x0, x, rnd, 3, f"pis phi4 d={d}", p0=0, pb=64)
+    assert bool(torch.isfinite(rnd).all())
 
 
 # ---- larger mixtures (K > 4): the workgroup-shared, double-buffered table copy -------------------------------------------
@@ -156,20 +132,7 @@ def test_shared_mixture_table(gpu, d, K, B):
     loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=d + K)
     loss.seed = 11
     x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw) if B >= 64 else loss.simulate(ts, x0, *args, **kw)
-    sde = orc.VP(0.1, 10.0, 1.0, 1.0)
-    tgt = orc.GMMDiag(info["target"].loc.cpu(), info["target"].scale.cpu(), info["target"].mixture_weights.cpu())
-    ctrl = orc.Ctrl(_sd(info["ctrl"]), "clipped", clip_model=1e4)
-    means, var, w = info["means"].cpu(), 0.5 * torch.ones(K, d), torch.ones(K)
-    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
-    refd = orc.GMMDiag(loc0, v0.sqrt(), w)
-    with torch.no_grad():
-        ox, ornd, _ = orc.simulate_ei_ref(ts.cpu(), x0[p0:p0 + pb].cpu(), ctrl, sde, tgt.logp, refd.logp,
-                                          lambda t, xx: orc.mog_score(xx, w, *sde.marginal_diag(t, means, var)),
-                                          orc.PhiloxNoise(11, particle0=p0))
-    x_err = gc.rel_err(x[p0:p0 + pb].cpu(), ox)
-    r_err = _rnd_err(rnd[p0:p0 + pb], ornd, max(1.0, float(tgt.logp(ox).abs().max())))
-    print(f"shared table d={d} K={K} B={B}: x_N {x_err:.2e}, rnd {r_err:.2e}")
-    assert x_err < 2e-4 and r_err < 2e-4
+    _block_vs_oracle("rds_gmm", info, ts, x0, x, rnd, 11, f"shared table d={d} K={K} B={B}", p0=p0, pb=pb)
 
 
 # ---- every kernel family at full occupancy --------------------------------------------------------------------------

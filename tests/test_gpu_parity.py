@@ -46,6 +46,36 @@ def sensitivity(name):
     return _AMP[name]
 
 
+# ---- 'identical seeds' (Philox) mode ----------------------------------------------------------------------------------
+# The kernel evaluates Box-Muller with the hardware's v_log / v_sin / v_cos: its normals differ from the oracle's libm evaluation
+# of the SAME counters by at most 1.2e-6 absolute (measured, test_philox_kernel_vs_oracle below; about
+# 2 ulp at |z| ~ 5).  What that does to x_N and the log-weights is a property of the case, measured here in the oracle itself:
+# the same trajectory with every normal moved by +-HW_NOISE_ERR.  The Philox-mode tests assert max(1e-5, 10 x that) and print
+# what they achieved -- 1e-5 wherever the case does not amplify (the north_star's bound), a stated larger bound where it does.
+HW_NOISE_ERR = 1.2e-6
+_NSENS = {}
+
+
+from oracle.baseline_oracles import PerturbedNoise  # noqa: E402  (a noise source moved by +-eps per normal, fixed sign pattern)
+
+
+def noise_sensitivity(name, eubo=False):
+    key = (name, eubo)
+    if key not in _NSENS:
+        c = gc.load(name)
+        run = gc.run_oracle_eubo if eubo else gc.run_oracle
+        base = orc.PhiloxNoise(c.meta["seed"])
+        x, r = run(c, noise=base)
+        x2, r2 = run(c, noise=PerturbedNoise(base))
+        scale = rnd_scale(c) if not eubo else torch.ones(1)
+        _NSENS[key] = max(gc.rel_err(x2, x), float(((r2.double() - r.double()).abs().view(-1, 1) / scale.double().view(-1, 1)).max()))
+    return _NSENS[key]
+
+
+def philox_tol(name, eubo=False):
+    return max(TOL, 10 * noise_sensitivity(name, eubo))
+
+
 def replay_noise(c, B=None):
     m = c.meta
     B = B or m["B"]
@@ -78,9 +108,9 @@ def test_philox_mode_matches_oracle(gpu, name):
     x, rnd, _ = b["loss"].simulate(b["ts"], b["x0"], *b["args"], **b["kwargs"])
     torch.cuda.synchronize()
     ex, ernd = gc.rel_err(x.cpu(), c["out_x"]), rnd_err(rnd, c)
-    print(f"{name}: philox-mode max rel err x_N {ex:.2e}, rnd {ernd:.2e}")
-    # hardware sin/cos/log2 in Box-Muller vs libm: ~1e-6 relative on z, amplified over the trajectory
-    tol = max(1e-4, 100 * sensitivity(name))
+    tol = philox_tol(name)
+    print(f"{name}: philox-mode max rel err x_N {ex:.2e}, rnd {ernd:.2e}   (tolerance {tol:.1e}; the case moves {noise_sensitivity(name):.1e} "
+          f"under a {HW_NOISE_ERR:.1e} perturbation of its normals)")
     assert ex < tol and ernd < tol
 
 
@@ -91,14 +121,14 @@ def test_compute_eubo_matches_reference_fixture(gpu, name):
     c = gc.load(name)
     b = bc.build(c, gpu)
     tgt_scale = torch.stack([fn(c["x0"].to(gpu)).view(-1).abs().cpu() for fn in b["args"]] + [c["rnd"].view(-1).abs()]).max(0).values.clamp(min=1.0)
-    for mode, noise, tol in (("injected", replay_noise(c).to(gpu), TOL), ("philox", None, 1e-4)):
+    for mode, noise, tol in (("injected", replay_noise(c).to(gpu), TOL), ("philox", None, philox_tol(name, eubo=True))):
         x = b["x0"].clone()
         extra = {k: v for k, v in b["kwargs"].items() if k == "initial_log_prob"}  # the DIS loss takes the prior log-density
         rnd = b["loss"].compute_eubo(b["ts"], x, *b["args"], noise=noise, **extra)
         torch.cuda.synchronize()
         ex = gc.rel_err(x.cpu(), c["out_x"]) if "out_x" in c.a else 0.0  # compute_eubo noises x in place, like the reference
         ernd = float(((rnd.cpu().view(-1) - c["rnd"].view(-1)).abs() / tgt_scale).max())
-        print(f"{name} [{mode}]: max rel err noised x {ex:.2e}, rnd {ernd:.2e}")
+        print(f"{name} [{mode}]: max rel err noised x {ex:.2e}, rnd {ernd:.2e}   (tolerance {tol:.1e})")
         assert ex < tol and ernd < tol
 
 
@@ -143,7 +173,7 @@ def test_philox_kernel_vs_oracle(gpu):
     ref = orc.philox_normal(12345678901234, 7, 1000, 300, 37)
     err = (out.cpu() - ref).abs().max().item()
     print("philox normal max abs err vs numpy:", err)
-    assert err < 5e-6
+    assert err < 2 * HW_NOISE_ERR
 
 
 @pytest.mark.gpu

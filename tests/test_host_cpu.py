@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "sdeng.h")).read()
-    declared = set(re.findall(r"\b(sdeng_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(sdeng_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     lib = ctypes.CDLL(L.LIB_PATH)
     for sym in sorted(declared):
@@ -30,9 +30,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header_layout():
     # sizes the C compiler produces for the same field lists (checked once with hipcc: see DESIGN.md)
-    assert ctypes.sizeof(L.Dist) == 56
+    assert ctypes.sizeof(L.Dist) == 64
     assert ctypes.sizeof(L.TimeEmbed) == 104
     assert ctypes.sizeof(L.Ref) == 40
+    assert ctypes.sizeof(L.Net) == 296 and ctypes.sizeof(L.Desc) == 728  # gcc on include/sdeng.h (ABI 3)
 
 
 def test_workspace_bytes_and_bad_descriptors_without_gpu():
