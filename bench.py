@@ -1,19 +1,23 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path: particle-steps/sec of one whole ``simulate`` (+ log-Z estimators).
+"""Benchmark of the hot path: particle-steps/sec of one whole ``simulate`` (+ log-Z estimators), and log-Z abs-err vs the reference.
 
-Workload (BASELINE.json configs[1]): ManyModes d=128 (K=4), RDS with a diagonal-GMM reference, VP(0.1,10),
-exponential integrator, 65 536 particles x 256 steps per GPU, FourierMLP drift net, in-kernel Philox noise.
-A "step" of this bench = one full pass: all 256 SDE steps of the batch, terminal cost, and the
-log-Z / ESS reduction (the window the reference times as eval/sample_time, solver/oc.py:148-158),
-inputs already resident in HBM.
+Headline workload (BASELINE.json configs[1]): ManyModes d=128 (K=4), RDS with a diagonal-GMM reference, VP(0.1,10),
+exponential integrator, 65 536 particles x 256 steps per GPU, FourierMLP drift net; x0 and the step noise are drawn in the kernel
+(Philox, keyed by the global particle index).  A "step" of this bench = one full pass: all 256 SDE steps of the batch, terminal cost,
+and the log-Z / ESS reduction (the window the reference times as eval/sample_time, solver/oc.py:148-158); nothing is read from HBM but
+the model (x0 is drawn in registers).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-For N>1 launch with torch.distributed.run (one rank per GPU, RCCL): the particle batch is sharded
-(weak scaling: 65 536 particles per rank, Philox counters keyed by the global particle index), no
-collective inside the step loop, one all_gather of rnd[B] for the final log-Z / ESS.
+For N>1 launch with torch.distributed.run (one rank per GPU, RCCL): the particle batch is sharded (weak scaling: 65 536 particles
+per rank), no collective inside the step loop, one 36-byte all-gather for the final log-Z / ESS.
 
-Prints ONE JSON line (rank 0) with the contract keys plus "roofline" and "cpu_baseline".
+Prints ONE JSON line (rank 0): the contract keys for the headline workload, plus
+  roofline       FP32-equivalent matrix roof of the step-loop kernel AND its instruction-issue roof (`issue`), HBM traffic (PMC)
+  cpu_baseline   the CPU oracle (a port of the reference's torch loop) on a bounded sample, host cores stated
+  log_z_abs_err  |log Z_HIP - log Z_oracle| on a block of 2 048 particles with identical seeds (x0 and noise), outside every timed window
+  other_configs  the same five items for configs[2] (PhiFour PIS, 131 072 x 512) and configs[3] (CMCD logistic regression, one GPU's
+                 shard 65 536 x 256) -- N = 1 only
 """
 from __future__ import annotations
 
@@ -30,6 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 MFMA = packed-fp32 vector peak (256 FLOP/clk/CU)
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+# Issue cost per instruction on one SIMD with two resident waves, ns (tools/ubench/valu_cost.hip, profiles/r01_ubench_valu_cost.log:
+# the "2w" column / 2).  MFMA and vector instructions of the waves of a SIMD do not overlap on gfx950
+# (profiles/r01_ubench_mfma_valu_serialize.log), so a SIMD's time per tile-step is at least the sum over classes of count x cost.
+ISSUE_NS = {"fp32 fma/mul/add": 1.335, "transcendental": 3.55, "int64 mad (Philox)": 2.00, "int32 mul": 2.0, "convert": 1.89,
+            "other vector (logic, select, move, cross-lane)": 1.14, "mfma 16x16x32 f16": 7.11}
+Z_BLOCK = 2048                 # particles of the log-Z parity block
 
 
 def host_cores() -> int:
@@ -49,41 +60,179 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(parts, N, seed, budget_s=15.0):
-    """The CPU oracle (a port of the reference's torch CPU loop, pinned to it by tests/golden) on a bounded
-    sample of the same workload, all host cores."""
+def oracle_leg(cfg, info, ts, hip_block, seed, N, cpu_budget_s, chunk):
+    """Everything that touches oracle/ (the checker): (a) log-Z / end-point parity of the HIP block against the oracle run with the
+    same seeds, (b) the CPU baseline -- the oracle timed on a bounded sample of the same workload, all host cores.  Neither is
+    inside a GPU-timed window."""
+    from oracle import baseline_oracles as bo
     from oracle import sde_oracle as orc
     cores = host_cores()
     torch.set_num_threads(cores)
-    sde = orc.VP(0.1, 10.0, 1.0, 1.0)
-    tgt = orc.GMMDiag(parts["target"].loc.cpu(), parts["target"].scale.cpu(), parts["target"].mixture_weights.cpu())
-    ctrl = orc.Ctrl({k: v.cpu() for k, v in parts["ctrl"].state_dict().items()}, "clipped", clip_model=1e4)
-    means, var, w = parts["means"].cpu(), 0.5 * torch.ones(parts["K"], parts["d"]), torch.ones(parts["K"])
+    run = bo.runner(cfg, info, ts)
+    out = {}
+    # (a) identical seeds: x0 = the engine's stream-1 draw, noise = its stream-0 draws, both restated on the CPU
+    hx, hrnd = hip_block
+    x0 = bo.initial_particles(cfg, info, seed, 0, hx.shape[0])
+    ox, ornd, scale = run(x0, orc.PhiloxNoise(seed, particle0=0))
+    lz_hip, lz_orc = bo.log_z(hrnd.cpu()), bo.log_z(ornd)
+    out["log_z_abs_err"] = abs(lz_hip - lz_orc)
+    out["parity"] = {"block": f"particles [0, {hx.shape[0]}) x {N} steps, identical seeds (x0: Philox stream 1, noise: stream 0)",
+                     "log_z_hip": lz_hip, "log_z_oracle": lz_orc,
+                     "x_N_max_rel_err": float(((hx.cpu() - ox).abs() / ox.abs().clamp(min=1.0)).max()),
+                     "rnd_max_err_rel_to_largest_summand": float((hrnd.cpu().flatten() - ornd.flatten()).abs().max()) / scale}
+    # (b) CPU baseline: torch's own generator for the noise, like the reference
+    if cpu_budget_s > 0:
+        d = info["d"]
+        gen = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            run(bo.initial_particles(cfg, info, seed, 0, 64), orc.TorchNoise())  # warm-up (thread pool, allocator)
+            done, wall = 0, 0.0
+            while wall < cpu_budget_s:
+                xc = torch.zeros(chunk, d) if cfg == "pis_phi4" else torch.randn(chunk, d, generator=gen)
+                if cfg == "cmcd_logreg":
+                    xc = info["mean"] + xc @ torch.linalg.cholesky(info["cov"]).T
+                t0 = time.perf_counter()
+                _, rnd, _ = run(xc, orc.TorchNoise())
+                orc.compute_results(rnd)
+                wall += time.perf_counter() - t0
+                done += chunk
+                print(f"[cpu_baseline {cfg}] {done} particles x {N} steps in {wall:.1f} s on {cores} threads", file=sys.stderr, flush=True)
+        out["cpu_baseline"] = dict(value=done * N / wall, unit="particle-steps/s", cores=torch.get_num_threads(), kind="port",
+                                   sample=f"{done} particles x {N} steps of the same workload (chunks of {chunk}), torch CPU fp32, {wall:.1f} s")
+    return out
 
-    def ref_score(t, x):
-        loc, v = sde.marginal_diag(t, means, var)
-        return orc.mog_score(x, w, loc, v)
 
-    loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
-    refd = orc.GMMDiag(loc0, v0.sqrt(), w)
-    ts = orc.get_timesteps(0.0, 1.0, steps=N)
-    gen = torch.Generator().manual_seed(seed)
-    chunk = 8192  # particles per call; chunks of the same workload are run until ~budget_s of CPU work is done
-    with torch.no_grad():
-        x0 = torch.randn(chunk, parts["d"], generator=gen)
-        orc.simulate_ei_ref(ts[:5], x0, ctrl, sde, tgt.logp, refd.logp, ref_score)  # warm-up (thread pool, allocator)
-        done, wall = 0, 0.0
-        while wall < budget_s and done < 65536:
-            x0 = torch.randn(chunk, parts["d"], generator=gen)
-            t0 = time.perf_counter()
-            _, rnd, _ = orc.simulate_ei_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score)
-            orc.compute_results(rnd)
-            wall += time.perf_counter() - t0
-            done += chunk
-            print(f"[cpu_baseline] {done} particles x {N} steps in {wall:.1f} s on {cores} threads", file=sys.stderr, flush=True)
-    B = done
-    return dict(value=B * N / wall, unit="particle-steps/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{B} particles x {N} steps of the same workload (chunks of {chunk}), torch CPU fp32, {wall:.1f} s")
+def roofline(cfg, info, B, N, k_ms, extra_flops=0):
+    """FP32-equivalent matrix roof (algorithmic drift-net FLOP at the dense FP32 rate) and the instruction-issue roof of the
+    step-loop kernel, from the committed PMC counters of the same workload (profiles/r02_pmc_<cfg>.json, tools/pmc_passes.sh)."""
+    flops_ps = info["flops"] + extra_flops
+    achieved = flops_ps * B * N / (k_ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+         "traffic": None, "kernel_ms": k_ms, "algorithmic_flops_per_particle_step": flops_ps,
+         "algorithmic_hbm_bytes_per_launch": (info["d"] + 1) * 4 * B + (0 if cfg != "cmcd_logreg" else info["d"] * 4 * B),
+         "note": "peak = dense FP32 MFMA/vector rate (an equivalence: results carry fp32 accuracy; the GEMMs are issued as a 3-product "
+                 "f16 split on v_mfma_f32_16x16x32_f16, 3x the algorithmic FLOP on the f16 pipe).  The binding resource is "
+                 "instruction issue: see `issue`."}
+    pj = os.path.join(ROOT, "profiles", f"r02_pmc_{cfg}.json")
+    from sde_sampler_lrds_amd.experiments.baseline_configs import FULL_SIZE
+    if os.path.exists(pj) and (B, N) == FULL_SIZE[cfg] and info.get("K", 4) == 4:
+        j = json.load(open(pj))
+        c = j["counters_per_launch"]
+        if j.get("traffic"):
+            r["traffic"] = j["traffic"]["bytes"]
+            r["traffic_unit"] = "bytes/launch"
+            r["traffic_source"] = f"profiles/r02_pmc_{cfg}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        tile_steps = ((B + 15) // 16) * N
+        fp = c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]
+        counts = {"fp32 fma/mul/add": fp, "transcendental": c["SQ_INSTS_VALU_TRANS_F32"], "int64 mad (Philox)": c["SQ_INSTS_VALU_INT64"],
+                  "int32 mul": c["SQ_INSTS_VALU_INT32"], "convert": c["SQ_INSTS_VALU_CVT"], "mfma 16x16x32 f16": c["SQ_INSTS_MFMA"]}
+        counts["other vector (logic, select, move, cross-lane)"] = max(0.0, c["SQ_INSTS_VALU"] - sum(counts.values()))
+        model_ms = sum(counts[k] * ISSUE_NS[k] for k in counts) / N_SIMD * 1e-6
+        r["issue"] = {"bound": "vector + matrix instruction issue per SIMD (they do not overlap on gfx950)",
+                      "instr_per_tile_step": {k: v / tile_steps for k, v in counts.items()},
+                      "vector_instr_per_tile_step": c["SQ_INSTS_VALU"] / tile_steps, "issue_cost_ns": ISSUE_NS,
+                      "model_ms": model_ms, "kernel_ms": k_ms, "frac": model_ms / k_ms,
+                      "source": f"profiles/r02_pmc_{cfg}.json (SQ_INSTS_* per launch), profiles/r01_ubench_valu_cost.log (cost per class)",
+                      "reading": "model_ms = sum over classes of count x issue cost / 1024 SIMDs: the time the kernel's own instruction "
+                                 "stream needs at full issue rate; frac = share of the kernel time it explains (the rest: LDS / scalar "
+                                 "waits, branches).  Faster means fewer instructions."}
+    return r
+
+
+def measure(cfg, device, B, N, steps, warmup, spinup, dist, rank, world, modes=4):
+    """Timed passes of one workload: W warm-up, K timed, barrier + synchronize on both sides, max over ranks."""
+    from sde_sampler_lrds_amd import _lib as L
+    from sde_sampler_lrds_amd import engine as E
+    from sde_sampler_lrds_amd import parallel
+    from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
+    kwb = dict(K=modes) if cfg == "rds_gmm" else {}
+    loss, ts, _, args, kw, info = cfgs.BUILDERS[cfg](device, 16, N, **kwb)  # the model; x0 is drawn by the engine
+    prior = cfgs.prior_of(cfg, info, device)
+    loss.seed = 1
+    loss.particle0 = rank * B  # global particle index -> sharding-independent x0 and noise
+    x0 = E.InitialDraw(prior, B, device)
+    ev = L.HipEvents()
+    loss.timing_events = ev
+
+    def one_pass():
+        """simulate + terminal cost + log-Z / ESS reduction (+ all-gather), all enqueued on the stream; the 36-byte
+        result is read back by .result() -- after the timed region for all but the last pass, so that consecutive
+        passes run back to back (a sampler in production does not idle the GPU between batches either)."""
+        _, rnd, _ = loss.simulate(ts, x0, *args, **kw)
+        return parallel.global_results_async(rnd, dist)
+
+    if dist is not None:  # create the RCCL communicator now (~20 ms the first time): an idle gap right before the timed
+        dist.barrier()    # region would let the clocks drop again
+        one_pass().result()
+        dist.barrier()
+    # bring the GPU to its sustained clocks first: the same pass, untimed (the first ~40 ms after idle run ~15 % slower than
+    # steady state); rank-local passes WITHOUT the all-gather: their number is time-based and may differ between ranks
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < spinup:
+        _, rnd_spin, _ = loss.simulate(ts, x0, *args, **kw)
+        parallel.global_results_async(rnd_spin, None).result()
+    for _ in range(warmup):
+        one_pass().result()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pending = [one_pass() for _ in range(steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    results = [p.result() for p in pending]  # every pass produced its estimators
+    assert all(math.isfinite(r["log_norm_const_is"]) for r in results)
+    if dist is not None:
+        wt = torch.tensor([wall], device=device)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        wall = wt.item()
+    # step-loop kernel duration: HIP events recorded by sdeng_simulate around that launch, on the launch stream
+    samples = [ev.elapsed_ms()]
+    for _ in range(min(5, steps)):
+        loss.simulate(ts, x0, *args, **kw)
+        samples.append(ev.elapsed_ms())
+    k_ms = sum(samples) / len(samples)
+    # the log-Z parity block (identical seeds), outside the timed region
+    loss.particle0 = 0
+    loss.timing_events = None
+    hx, hrnd, _ = loss.simulate(ts, E.InitialDraw(prior, Z_BLOCK, device), *args, **kw)
+    torch.cuda.synchronize()
+    return dict(cfg=cfg, B=B, N=N, info=info, ts=ts, wall=wall, steps=steps, value=world * B * N * steps / wall, ms_per_step=1e3 * wall / steps,
+                kernel_ms=k_ms, res=results[-1], hip_block=(hx, hrnd), seed=1)
+
+
+def path_of(cfg, info):
+    if cfg == "rds_gmm":
+        K = info["K"]
+        small = K <= 4 and K * 2 * 16 * ((info["d"] + 15) // 16) <= 1024
+        return (f"k_simulate<NT={(info['d'] + 15) // 16},REF={'GMM' if small else 'GMM_BIG'},SC=NONE,FORM=LIN>: "
+                + ("K <= 4: responsibilities in registers, per-wave LDS table by LDS-DMA; all components share one variance vector "
+                   "(variances_init = 0.5, the reference's default initialisation) -> shared-variance score form "
+                   "(a fitted reference with distinct variances runs the general form, ~2-3 % slower)" if small
+                   else "K > 4: workgroup-shared double-buffered LDS table, online softmax"))
+    if cfg == "pis_phi4":
+        return f"k_simulate<NT={(info['d'] + 15) // 16},REF=NONE,SC=PHI4,FORM=EM>: ScoreCtrl with the phi^4 lattice score in registers (neighbour exchange by cross-lane moves)"
+    return ("k_simulate_cmcd<NT=4,LOGREG>: one drift-net + one annealed-score evaluation per step (the reference: 2 + 4), design matrix in "
+            "LDS as split-f16 MFMA images, full-covariance prior precision through L2")
+
+
+def config_entry(m, cpu_budget_s, chunk, with_cpu):
+    cfg, info = m["cfg"], m["info"]
+    extra = 0
+    if cfg == "cmcd_logreg":  # logits + gradient products of the logistic-regression score and the prior precision product, per step
+        extra = 2 * 2 * info["X"].shape[0] * info["d"] + 2 * info["d"] ** 2
+    e = {"workload": info["workload"] + f", {m['B']} particles x {m['N']} steps", "particles": m["B"], "sde_steps": m["N"],
+         "value": m["value"], "unit": "particle-steps/s", "ms_per_step": m["ms_per_step"], "steps": m["steps"], "kernel_ms": m["kernel_ms"],
+         "path": path_of(cfg, info), "log_norm_const_is": m["res"]["log_norm_const_is"], "ess": m["res"]["ess"],
+         "roofline": roofline(cfg, info, m["B"], m["N"], m["kernel_ms"], extra)}
+    e.update(oracle_leg(cfg, info, m["ts"], m["hip_block"], m["seed"], m["N"], cpu_budget_s if with_cpu else 0.0, chunk))
+    if "cpu_baseline" in e:
+        e["speedup_vs_cpu"] = e["value"] / e["cpu_baseline"]["value"]
+    return e
 
 
 def main():
@@ -91,10 +240,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--particles", type=int, default=65536, help="per GPU")
+    ap.add_argument("--particles", type=int, default=65536, help="per GPU (headline workload)")
     ap.add_argument("--sde-steps", type=int, default=256)
     ap.add_argument("--modes", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed passes before the warm-up (clock ramp)")
     a = ap.parse_args()
 
@@ -110,94 +260,32 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    from sde_sampler_lrds_amd import _lib as L
-    from sde_sampler_lrds_amd import parallel
     B, N = a.particles, a.sde_steps
-    from sde_sampler_lrds_amd.experiments.baseline_configs import build_rds_gmm
-    loss, ts, x0, args, _, parts = build_rds_gmm(device, B, N, K=a.modes, seed=1, x_seed=1 + rank)  # one sampler, rank-specific particles
-    flops_ps = parts["flops"]
-    loss.seed = 1
-    loss.particle0 = rank * B  # global particle index -> sharding-independent noise
-    ev = L.HipEvents()
-    loss.timing_events = ev
-
-    def one_pass():
-        """simulate + terminal cost + log-Z / ESS reduction (+ all-gather), all enqueued on the stream; the 36-byte
-        result is read back by .result() -- after the timed region for all but the last pass, so that consecutive
-        passes run back to back (a sampler in production does not idle the GPU between batches either)."""
-        x, rnd, _ = loss.simulate(ts, x0, *args)
-        return parallel.global_results_async(rnd, dist)
-
-    if dist is not None:  # create the RCCL communicator now (~20 ms the first time): an idle gap right before the timed
-        dist.barrier()    # region would let the clocks drop again
-        one_pass().result()
-        dist.barrier()
-    # bring the GPU to its sustained clocks first: the same pass, untimed (the first ~40 ms after idle run ~15 %
-    # slower than steady state: tools/probe_scaling.py)
-    # (rank-local passes WITHOUT the all-gather: the number of spin-up passes is time-based and may differ between ranks)
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < a.spinup:
-        _, rnd_spin, _ = loss.simulate(ts, x0, *args)
-        parallel.global_results_async(rnd_spin, None).result()
-    for _ in range(a.warmup):
-        one_pass().result()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pending = [one_pass() for _ in range(a.steps)]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    results = [p.result() for p in pending]  # every pass produced its estimators
-    res = results[-1]
-    assert all(math.isfinite(r["log_norm_const_is"]) for r in results)
-    if dist is not None:
-        wt = torch.tensor([wall], device=device)
-        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
-        wall = wt.item()
-    # step-loop kernel duration: last pass's events (HIP events on the launch stream)
-    k_ms = ev.elapsed_ms()
-    # a few more individually timed launches for the average
-    samples = [k_ms]
-    for _ in range(min(5, a.steps)):
-        loss.simulate(ts, x0, *args)
-        samples.append(ev.elapsed_ms())
-    k_ms = sum(samples) / len(samples)
-
-    value = world * B * N * a.steps / wall
-    out = None
+    head = measure("rds_gmm", device, B, N, a.steps, a.warmup, a.spinup, dist, rank, world, modes=a.modes)
+    others = []
+    if world == 1 and not a.no_other_configs:
+        from sde_sampler_lrds_amd.experiments.baseline_configs import FULL_SIZE
+        for cfg in ("pis_phi4", "cmcd_logreg"):
+            others.append(measure(cfg, device, *FULL_SIZE[cfg], a.steps, a.warmup, a.spinup, None, 0, 1))
     if rank == 0:
-        achieved = flops_ps * B * N / (k_ms * 1e-3) / 1e12
-        # HBM bytes per launch cannot be counted from inside this process: the figure is the committed rocprofv3 PMC
-        # measurement of this same workload (tools/pmc_passes.sh), reported only when the workload is the one measured
-        traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01_pmc_cfg2_traffic.json")
-        if os.path.exists(tj) and (B, N, a.modes) == (65536, 256, 4):
-            traffic, traffic_src = json.load(open(tj))["bytes"], "profiles/r01_pmc_cfg2_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        with_cpu = world == 1 and not a.no_cpu_baseline
+        e = config_entry(head, 15.0, 8192, with_cpu)
         out = {
-            "metric": "particle-steps/sec (batch*n_steps/wall)", "value": value, "unit": "particle-steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps,
+            "metric": "particle-steps/sec (batch*n_steps/wall) + log-Z abs-err vs ref", "value": head["value"], "unit": "particle-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ManyModes d=128 K={a.modes}, RDS gmm-ref, VP(0.1,10), EI integrator, "
-                                   f"{B} particles x {N} steps per GPU, FourierMLP(4x64) drift, Philox noise",
+                                   f"{B} particles x {N} steps per GPU, FourierMLP(4x64) drift, x0 and noise drawn in-kernel (Philox)",
                        "particles_per_gpu": B, "sde_steps": N, "parallelism": f"particle-sharded x{world}"},
-            "log_norm_const_is": res["log_norm_const_is"], "ess": res["ess"], "spinup_s": a.spinup,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "algorithmic_hbm_bytes_per_launch": (2 * 128 + 1) * 4 * B,
-                         "kernel": f"k_simulate<NT=8,REF={'GMM' if a.modes <= 4 else 'GMM_BIG'},SC=NONE,FORM=LIN> (one launch = all sde_steps of the batch)",
-                         "kernel_ms": k_ms, "algorithmic_flops_per_particle_step": flops_ps,
-                         "note": "peak = dense FP32 MFMA/vector rate: results carry fp32 accuracy; the GEMMs are issued as a "
-                                 "3-product f16-split on v_mfma_f32_16x16x32_f16 (3x the algorithmic FLOP on the f16 pipe)"},
+            "log_z_abs_err": e["log_z_abs_err"], "parity": e["parity"], "path": e["path"],
+            "log_norm_const_is": e["log_norm_const_is"], "ess": e["ess"], "spinup_s": a.spinup, "roofline": e["roofline"],
         }
-        if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(parts, N, seed=1)
-            out["cpu_baseline"] = cb
-            out["speedup_vs_cpu"] = value / cb["value"]
+        out["roofline"]["kernel"] = e["path"].split(":")[0] + " (one launch = all sde_steps of the batch)"
+        if "cpu_baseline" in e:
+            out["cpu_baseline"] = e["cpu_baseline"]
+            out["speedup_vs_cpu"] = e["speedup_vs_cpu"]
+        if others:
+            out["other_configs"] = [config_entry(m, 8.0, 4096 if m["cfg"] == "pis_phi4" else 2048, with_cpu) for m in others]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

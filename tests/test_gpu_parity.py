@@ -50,7 +50,7 @@ def sensitivity(name):
 # The kernel evaluates Box-Muller with the hardware's v_log / v_sin / v_cos: its normals differ from the oracle's libm evaluation
 # of the SAME counters by at most 1.2e-6 absolute (measured, test_philox_kernel_vs_oracle below; about
 # 2 ulp at |z| ~ 5).  What that does to x_N and the log-weights is a property of the case, measured here in the oracle itself:
-# the same trajectory with every normal moved by +-HW_NOISE_ERR.  The Philox-mode tests assert max(1e-5, 10 x that) and print
+# the same trajectory with every normal moved by +-HW_NOISE_ERR (random signs; the worst of two patterns).  The Philox-mode tests assert max(1e-5, 10 x that) and print
 # what they achieved -- 1e-5 wherever the case does not amplify (the north_star's bound), a stated larger bound where it does.
 HW_NOISE_ERR = 1.2e-6
 _NSENS = {}
@@ -66,9 +66,12 @@ def noise_sensitivity(name, eubo=False):
         run = gc.run_oracle_eubo if eubo else gc.run_oracle
         base = orc.PhiloxNoise(c.meta["seed"])
         x, r = run(c, noise=base)
-        x2, r2 = run(c, noise=PerturbedNoise(base))
         scale = rnd_scale(c) if not eubo else torch.ones(1)
-        _NSENS[key] = max(gc.rel_err(x2, x), float(((r2.double() - r.double()).abs().view(-1, 1) / scale.double().view(-1, 1)).max()))
+        worst = 0.0
+        for salt in range(2):  # two independent sign patterns: amplification near a separatrix is hit-or-miss
+            x2, r2 = run(c, noise=PerturbedNoise(base, salt=salt))
+            worst = max(worst, gc.rel_err(x2, x), float(((r2.double() - r.double()).abs().view(-1, 1) / scale.double().view(-1, 1)).max()))
+        _NSENS[key] = worst
     return _NSENS[key]
 
 
