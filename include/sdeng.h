@@ -188,8 +188,9 @@ typedef struct sdeng_ref {
  *     ISO_GAUSS   x0 = p0 + p1 * z                IsotropicGauss.sample   distr/gauss.py:772-787 (no truncation)
  *     GAUSS_DIAG  x0 = loc + scale * z            Gauss.sample distr/gauss.py:235-239;  scale == NULL: x0 = loc  (Delta.sample, distr/delta.py:27-31)
  *     GAUSS_FULL  x0 = loc + L z  (L = aux)       GaussFull.sample        distr/gauss.py:709-713 (MultivariateNormal)
- *   ISO_GAUSS / GAUSS_DIAG without FLAG_INIT_LOGP are drawn in registers by the step-loop kernel itself (x0 never touches HBM);
- *   otherwise x0 is first materialised in the workspace.  x0_out (optional, [B,d]) receives the drawn x0 either way.
+ *   ISO_GAUSS / GAUSS_DIAG are drawn in registers by the step-loop kernel itself (x0 never touches HBM) in the plain sampling
+ *   call -- forward form, no FLAG_INIT_LOGP, no xs_out / noise_in, diagonal or no reference; otherwise x0 is first materialised in
+ *   the workspace (same values).  x0_out (optional, [B,d]) receives the drawn x0 either way.
  */
 typedef struct sdeng_desc {
   int32_t abi_version;   /* SDENG_ABI_VERSION                                              */

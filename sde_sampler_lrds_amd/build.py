@@ -71,6 +71,22 @@ def sources():
     return srcs
 
 
+def _resource_remarks(stderr):
+    """-Rpass-analysis=kernel-resource-usage remarks -> [{name, VGPRs, ScratchSize..., Occupancy...}]"""
+    import re
+    out, cur = [], None
+    for line in stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = {"name": m.group(1)}
+            out.append(cur)
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
 def _write_if_changed(path, body):
     if os.path.exists(path) and open(path).read() == body:
         return
@@ -97,16 +113,25 @@ def build(jobs: int | None = None, force: bool = False, verbose: bool = True) ->
     srcs = sources()
     jobs = jobs or min(8, os.cpu_count() or 1)
 
+    usage = {}
+
     def compile_one(src):
         obj = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+        cmd = [HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        usage[os.path.basename(src)] = _resource_remarks(r.stderr)
         return obj
 
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(compile_one, srcs))
+    with open(os.path.join(OBJ, "kernel_resources.txt"), "w") as f:  # registers / scratch / occupancy of every kernel (compiler remarks)
+        f.write("# unit kernel VGPRs AGPRs scratch_bytes_per_lane occupancy_waves_per_SIMD LDS_bytes\n")
+        for unit in sorted(usage):
+            for k in usage[unit]:
+                f.write(f"{unit} {k['name']} {k.get('VGPRs', '?')} {k.get('AGPRs', '?')} {k.get('ScratchSize [bytes/lane]', '?')} "
+                        f"{k.get('Occupancy [waves/SIMD]', '?')} {k.get('LDS Size [bytes/block]', '?')}\n")
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -47,7 +47,9 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
     gmm_score<NT>(x, s.target.tab, s.target.consts, 4, s.target.k, s.target.p0, g, ts);
   } else {
     static_assert(TGT != CT_LOGREG || NT <= 4, "logistic regression: d <= 64 (design matrix in LDS)");
-    logreg_score<NT>(x, xh, xl, s.lr, s.d, lds + sd_lds_weight_floats(NT), lane, ts);
+    // (two copies of the body on purpose: a pointer selected between LDS and global memory would make every A-operand read a flat load)
+    if (s.lr.in_lds) logreg_score<NT>(x, xh, xl, s.lr, s.d, lds + sd_lds_weight_floats(NT), lane, ts);
+    else logreg_score<NT>(x, xh, xl, s.lr, s.d, s.lr.image, lane, ts);
   }
 
   // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
   {
     const int nw = sd_lds_weight_floats(NT);
     for (int i = tid; i < nw / 4; i += SD_THREADS) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(s.wpack)[i];
-    const int ni = sd_lr_floats(NT, s.lr.n_rows);
+    const int ni = s.lr.in_lds ? sd_lr_floats(NT, s.lr.n_rows) : 0;
     for (int i = tid; i < ni / 4; i += SD_THREADS) reinterpret_cast<f32x4*>(lds + nw)[i] = reinterpret_cast<const f32x4*>(s.lr.image)[i];
   }
   __syncthreads();
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     const bool live = row < static_cast<uint32_t>(s.B);
     const uint32_t pidx = static_cast<uint32_t>(s.particle0 + row);
     f32x4 x[NT];
-    initial_state<NT>(s, row, pidx, live, g, trash, x);
+    load_rows<NT>(s.x_in, row, s.d, live, g, x);  // (x0 drawn by the engine is materialised first: the initial log-density needs it, sdeng_api.hip)
     float rnd = 0.0f;
     if (s.rnd_init) rnd = (live ? s.rnd_init[row] : 0.0f);  // rnd0 = log p_prior(x0)  (losses/oc.py:695-699)
     if (s.xs_out) store_rows<NT>(s.xs_out, trash, row, s.d, live, g, x);
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
 
 template <int NT, int TGT, bool EUBO>
 static int launch_cmcd_t(const CmcdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(cmcd_lds_floats(NT, a.s.lr.n_rows)) * sizeof(float);
+  const size_t lds_bytes = static_cast<size_t>(a.s.lr.in_lds ? cmcd_lds_floats(NT, a.s.lr.n_rows) : sd_lds_weight_floats(NT)) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT, TGT, EUBO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(SD_EULER_THREADS) k_euler(const SimArgs a) {
     const bool live = row < static_cast<uint32_t>(a.B);
     const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
     f32x4 x[NT];
-    initial_state<NT>(a, row, pidx, live, g, trash, x);
+    load_rows<NT>(a.x_in, row, a.d, live, g, x);
     if (a.xs_out) store_rows<NT>(a.xs_out, trash, row, a.d, live, g, x);
     for (int k = 0; k < a.N; ++k) {
       const float* cf = a.coef + static_cast<size_t>(k) * SDENG_NCOEF;

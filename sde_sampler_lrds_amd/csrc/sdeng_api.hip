@@ -106,7 +106,8 @@ static size_t dist_floats(const sdeng_dist& ds, int dpad) {
 // x_in == NULL: is x0 written to memory before the step loop (workspace or x0_out), or drawn in registers by the kernel?
 // In registers for ISO_GAUSS / GAUSS_DIAG unless the initial log-density is needed (it is evaluated from x0 in memory).
 static bool x0_materialised(const sdeng_desc* d) {
-  return d->x0_dist.kind == SDENG_DIST_GAUSS_FULL || (d->flags & SDENG_FLAG_INIT_LOGP) || d->form == SDENG_FORM_CMCD;
+  return d->x0_dist.kind == SDENG_DIST_GAUSS_FULL || (d->flags & SDENG_FLAG_INIT_LOGP) || d->form == SDENG_FORM_CMCD ||
+         d->xs_out || d->noise_in || d->ref.kind == SDENG_REF_GMM_FULL || d->net.ctrl_kind == SDENG_CTRL_NONE;
 }
 static int check_x0_dist(const sdeng_desc* d);
 
@@ -286,6 +287,8 @@ static int prepare_logreg(const sdeng_desc* d, const Layout& L, float* ws, int D
   if (n < 1 || !d->target.loc || !d->target.scale) return fail(SDENG_E_INVALID, "LOGREG needs X, y and k >= 1 rows");
   SD_HIP(sd_launch_logreg_images(d->target.loc, d->target.scale, n, d->d - 1, DT, image, y_pad, s));
   a.lr.image = image; a.lr.y_pad = y_pad; a.lr.n_rows = n;
+  // sonar (166 x 61) sits in LDS next to the drift net; larger design matrices (credit: 800 rows) are read through L2 instead
+  a.lr.in_lds = static_cast<size_t>(cmcd_lds_floats(DT, n)) * sizeof(float) <= 160 * 1024 ? 1 : 0;
   a.lr.inv_w_scale2 = 1.0f / (d->target.p0 * d->target.p0); a.lr.c_mean = d->target.p1; a.lr.inv_c_scale2 = 1.0f / (d->target.p2 * d->target.p2);
   // sigmoid range with a gradient: inside clip(thr, 1 - thr) and inside the eps clamp of probs_to_logits
   const float thr = d->target.p3, eps = 1.1920928955078125e-07f;
@@ -303,9 +306,6 @@ static int simulate_cmcd(const sdeng_desc* d, const Layout& L, float* ws, int DT
   if (logreg && DT > 4) return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: logistic regression with d <= 64 (got %d)", d->d);
   const int n = logreg ? d->target.k : 0;  // data rows held in LDS
   if (logreg && n < 1) return fail(SDENG_E_INVALID, "CMCD kernel: logistic regression without data rows");
-  if (static_cast<size_t>(cmcd_lds_floats(DT, n)) * sizeof(float) > 160 * 1024)
-    return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: drift net + design matrix (%d rows x %d) need %zu bytes of LDS, 163840 available", n, d->d,
-                static_cast<size_t>(cmcd_lds_floats(DT, n)) * sizeof(float));
   if (d->prior.kind != SDENG_DIST_GAUSS_FULL && d->prior.kind != SDENG_DIST_ISO_GAUSS && d->prior.kind != SDENG_DIST_GAUSS_DIAG)
     return fail(SDENG_E_UNSUPPORTED, "CMCD kernel: prior must be GAUSS_FULL, GAUSS_DIAG or ISO_GAUSS (kind %d)", d->prior.kind);
   if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && d->net.ctrl_kind != SDENG_CTRL_SCORE)
@@ -546,9 +546,6 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     float* unused;
     rc = prepare_logreg(d, L, ws, DT, a, s, &unused);
     if (rc) return rc;
-    const size_t lds = (static_cast<size_t>(sd_lds_weight_floats(DT)) + sd_lr_floats(DT, a.lr.n_rows)) * sizeof(float);
-    if (lds > 160 * 1024)
-      return fail(SDENG_E_UNSUPPORTED, "drift net + design matrix (%d rows x %d) need %zu bytes of LDS, 163840 available", a.lr.n_rows, d->d, lds);
     fn = kLogregTable[dt_index(DT)][d->form];
   } else if (rf == RF_GMM_FULL) {
     if (sc != SC_NONE) return fail(SDENG_E_UNSUPPORTED, "full-covariance reference together with a Score/LerpCtrl");

@@ -73,6 +73,7 @@ struct LogregDev {
   float inv_w_scale2, c_mean, inv_c_scale2;   // 1/weight_scale^2, intercept_mean, 1/intercept_scale^2
   float p_lo, p_hi;         // sigmoid range with non-zero gradient (clip threshold and eps clamp)
   int n_rows;               // data rows n (0: no logistic-regression target)
+  int in_lds;               // 1: the two images fit behind the drift-net weights in LDS; 0: the kernel reads them through L2
 };
 
 // initial particles drawn by the engine (sdeng_desc.x_in == NULL): x0 = loc + scale * z, z = Philox stream 1 at step 0

@@ -414,8 +414,15 @@ SD_INLINE f32x4 x0_quad(const X0Dev& q, uint32_t pidx, int jb, int d, uint32_t k
 }
 template <int NT>
 SD_INLINE void draw_x0(const SimArgs& a, uint32_t pidx, int g, f32x4 (&x)[NT]) {
+  // The draw sits at the top of the persistent tile loop and nothing in it but `pidx` changes from tile to tile: left alone, the
+  // compiler hoists the loc / scale loads and the key-only part of the Philox rounds out of that loop and keeps them in registers for
+  // the whole kernel.  Re-reading the parameters through an opaque move per tile pins the work to where it is used.
+  X0Dev q = a.x0;
+  uint32_t k0 = a.seed_lo, k1 = a.seed_hi;
+  int d = a.d;
+  asm volatile("" : "+s"(q.loc), "+s"(q.scale), "+s"(q.p0), "+s"(q.p1), "+s"(k0), "+s"(k1), "+s"(d));
 #pragma unroll
-  for (int t = 0; t < NT; ++t) x[t] = x0_quad(a.x0, pidx, 4 * t + g, a.d, a.seed_lo, a.seed_hi);
+  for (int t = 0; t < NT; ++t) x[t] = x0_quad(q, pidx, 4 * t + g, d, k0, k1);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -713,10 +720,13 @@ SD_INLINE void store_rows(float* __restrict__ dst, float* __restrict__ trash, ui
 #pragma unroll
   for (int t = 0; t < NT; ++t) store_quad(dst, trash, row, d, live, t, g, v[t]);
 }
-// x0 of a tile: read from x_in, or drawn in registers (and optionally written to x0_out)
-template <int NT>
+// x0 of a tile: read from x_in (X0 = 0), or drawn in registers and optionally written to x0_out (X0 = 1).  The draw is a
+// template parameter of the step-loop kernel, not a run-time branch: with both paths in one kernel the register allocator paid for the
+// draw's prologue peak in every instantiation (+30-40 VGPRs, scratch in 87 of them) -- so only the forward, no-trajectory kernels
+// have an X0 = 1 twin, and everything else gets its drawn x0 from memory (sdeng_api.hip x0_materialised).
+template <int NT, int X0>
 SD_INLINE void initial_state(const SimArgs& a, uint32_t row, uint32_t pidx, bool live, int g, float* trash, f32x4 (&x)[NT]) {
-  if (a.x0.kind == SDENG_DIST_NONE) {
+  if constexpr (X0 == 0) {
     load_rows<NT>(a.x_in, row, a.d, live, g, x);
   } else {
     draw_x0<NT>(a, pidx, g, x);

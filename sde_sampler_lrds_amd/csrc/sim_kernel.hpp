@@ -64,7 +64,8 @@ SD_INLINE void add_ctrl_score_tile(const SimArgs& a, f32x4& u, const f32x4& sv, 
 }
 
 // PAR = 1 adds the parity-mode paths (injected noise, trajectory dump); PAR = 0 keeps them out of the step loop.
-template <int NT, int REF, int SC, int FORM, int PAR>
+// X0 = 1 draws the initial particles in registers (sim_device.hpp initial_state); only PAR = 0 forward kernels have that twin.
+template <int NT, int REF, int SC, int FORM, int PAR, int X0 = 0>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const SimArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int dpad = 16 * NT;
@@ -76,8 +77,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     const int n4 = sd_lds_weight_floats(NT) / 4;
     for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
-    if constexpr (SC == SC_LOGREG) {  // the two design-matrix images behind the weights
-      const int ni = sd_lr_floats(NT, a.lr.n_rows) / 4;
+    if constexpr (SC == SC_LOGREG) {  // the two design-matrix images behind the weights (when they fit: else they stay in L2)
+      const int ni = a.lr.in_lds ? sd_lr_floats(NT, a.lr.n_rows) / 4 : 0;
       for (int i = tid; i < ni; i += SD_THREADS) dst[n4 + i] = reinterpret_cast<const f32x4*>(a.lr.image)[i];
     }
   }
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     const bool live = row < static_cast<uint32_t>(a.B);
     const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
     f32x4 x[NT];
-    initial_state<NT>(a, row, pidx, live, g, trash, x);
+    initial_state<NT, X0>(a, row, pidx, live, g, trash, x);
     // rnd0 = log p_prior(x0) when the loss asks for it (losses/oc.py:695-699, 935-939), from k_dist_eval
     float rnd = 0.0f;
     if (a.rnd_init) rnd = (live ? a.rnd_init[row] : 0.0f);
@@ -198,7 +199,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         asm volatile("" ::: "memory");
         f16x8 xh[(NT + 1) / 2], xl[(NT + 1) / 2];
         split_tiles<NT>(x, xh, xl);
-        logreg_score<NT>(x, xh, xl, a.lr, d_dyn, lds + sd_lds_weight_floats(NT), lane, ts);
+        // two copies of the body on purpose: a pointer selected between LDS and global memory would turn every A-operand read into a flat load
+        if (a.lr.in_lds) logreg_score<NT>(x, xh, xl, a.lr, d_dyn, lds + sd_lds_weight_floats(NT), lane, ts);
+        else logreg_score<NT>(x, xh, xl, a.lr, d_dyn, a.lr.image, lane, ts);
       }
       // reference drift (eq/sdes.py:265-279, 329-345): small mixtures keep only the K responsibilities and
       // assemble the score tile by tile in the tail; larger ones use the online-softmax accumulator
@@ -465,19 +468,25 @@ static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
   int sd_launch_ctrl_##NT##_##SC(const SimArgs& a, int grid, hipStream_t s) { return launch_ctrl_forward<NT, SC>(a, grid, s); }
 
 // host-side launcher, one per instantiation (defined in gen/sim_*.hip)
-template <int NT, int REF, int SC, int FORM, int PAR>
+template <int NT, int REF, int SC, int FORM, int PAR, int X0 = 0>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM)) +
-                           (SC == SC_LOGREG ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0) +
+                           ((SC == SC_LOGREG && a.lr.in_lds) ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0) +
                            ((REF == RF_GMM_BIG || REF == RF_GMM_FULL) ? sizeof(float) * 2 * sd_share_buf_floats(a.ref_share) : 0);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR, X0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_simulate<NT, REF, SC, FORM, PAR>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_simulate<NT, REF, SC, FORM, PAR, X0>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
 }
 template <int NT, int REF, int SC, int FORM>
 static int launch_simulate(const SimArgs& a, int grid, hipStream_t stream) {
+  if (a.x0.kind != SDENG_DIST_NONE) {  // x0 drawn in registers: sdeng_api.hip (x0_materialised) only asks for it where the twin exists
+    if constexpr (FORM != SDENG_FORM_EUBO && REF != RF_GMM_FULL) {
+      if (!a.noise_in && !a.xs_out) return launch_simulate_par<NT, REF, SC, FORM, 0, 1>(a, grid, stream);
+    }
+    return static_cast<int>(hipErrorInvalidValue);
+  }
   if (a.noise_in || a.xs_out) return launch_simulate_par<NT, REF, SC, FORM, 1>(a, grid, stream);
   return launch_simulate_par<NT, REF, SC, FORM, 0>(a, grid, stream);
 }

@@ -10,6 +10,7 @@ from functools import partial
 import torch
 
 from ..distr.gauss import BracketTwoModes, ManyModes, TwoModes, TwoModesFull
+from ..distr.logistic_regression import LogisticRegression
 from ..distr.phi_four import PhiFour
 from ..distr.rings import Rings
 from ..solver import oc
@@ -30,6 +31,15 @@ _SOLVERS = {
 }
 
 
+# conf/target/{sonar,ionosphere,cancer,credit}.yaml
+LOGREG_TARGETS = {
+    "sonar": dict(dim=61, data_type="sonar", intercept_mean=-2.5, intercept_scale=0.5, weight_scale=4.5),
+    "ionosphere": dict(dim=34, data_type="ionosphere", intercept_mean=4.25, intercept_scale=0.25, weight_scale=5.25),
+    "cancer": dict(dim=31, data_type="cancer", intercept_mean=31.0, intercept_scale=2.0, weight_scale=3.75),
+    "credit": dict(dim=25, data_type="credit", intercept_mean=3.25, intercept_scale=0.5, weight_scale=1.25),
+}
+
+
 def make_target_details(target_name, **kwargs):
     """experiments/benchmark_utils.py:41-93 (targets with a HIP kernel)."""
     if target_name == "two_modes":
@@ -45,6 +55,8 @@ def make_target_details(target_name, **kwargs):
         return dict(name="phi_four", dim=kwargs.get("dim", 100), b=kwargs.get("b", 0.0))
     if target_name == "rings":
         return dict(name="rings")
+    if target_name in LOGREG_TARGETS:  # benchmark_utils.py:84-91
+        return dict(name=target_name)
     raise NotImplementedError(f"Target {target_name} not supported by the HIP engine.")
 
 
@@ -63,6 +75,8 @@ def _make_target(details):
         return PhiFour(**{"dim": 100, "a": 0.1, "b": 0.0, "dim_phys": 1, "beta": 20.0, **d})
     if name == "rings":  # conf/target/rings.yaml
         return Rings(**{"dim": 2, "n_reference_samples": 10000, **d})
+    if name in LOGREG_TARGETS:  # the design matrix: register_dataset / $SDENG_DATA_DIR/<name>.pt (distr/logistic_regression.py)
+        return LogisticRegression(**{**LOGREG_TARGETS[name], **d})
     if "object" in details:
         return details["object"]
     raise NotImplementedError(name)

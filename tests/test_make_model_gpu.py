@@ -129,3 +129,92 @@ def test_smc_and_replica_exchange_on_hip_densities(gpu):
     assert rs.shape == (n_levels, 8, 512, d) and bool(torch.isfinite(rs).all()) and 0.0 <= float(rd["swap_acc"]) <= 1.0
     near = torch.cdist(rs[0, -1], loc.to(gpu)).min(dim=1).values
     assert float(near.mean()) < 2.0  # the t = 1 level stays on the modes
+
+
+# ---- Bayesian logistic-regression targets through the drop-in make_model (BASELINE.json configs[3]) -----------------------------
+# The reference's data/*.pkl are pickles and are never loaded: the design matrices here are synthetic, of each data set's
+# feature count (conf/target/*.yaml: dim - 1) and a plausible number of rows; parity on the REAL data is unpinned.
+LOGREG_SHAPES = {"sonar": (166, 60), "ionosphere": (280, 33), "cancer": (455, 30), "credit": (800, 24)}
+
+
+def _synthetic_logreg(name, seed=7):
+    n, f = LOGREG_SHAPES[name]
+    g = torch.Generator().manual_seed(seed + n)
+    X = (1e-4 + (1 - 1e-4) * torch.rand(n, f, generator=g) ** 2).float()
+    y = (torch.rand(n, generator=g) < 0.47).float()
+    return X, y
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sonar", "ionosphere", "cancer", "credit"])
+def test_make_model_cmcd_on_logistic_regression_targets(gpu, name):
+    """make_model('cmcd', 'gaussian', 'lv', 'em', 'target_informed_zero_init', 'uniform', ...) -- experiments/benchmark_utils.py:96-265
+    with target 'sonar' | 'ionosphere' | 'cancer' | 'credit' (:84-91) -- builds, evaluates and takes a training step on the HIP engine.
+    sonar's design matrix sits in LDS; the larger ones are read through L2 (sdeng_api.hip prepare_logreg)."""
+    from sde_sampler_lrds_amd.distr.logistic_regression import LogisticRegression, register_dataset
+    from sde_sampler_lrds_amd.experiments.benchmark_utils import LOGREG_TARGETS
+    X, y = _synthetic_logreg(name)
+    register_dataset(name, X, y)
+    d = LOGREG_TARGETS[name]["dim"]
+    assert X.shape[1] + 1 == d
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(d, d, generator=g)
+    details = dict(mean=0.1 * torch.randn(d, generator=g), var=0.01 * A @ A.T + 0.5 * torch.eye(d))
+    model = make_model("cmcd", "gaussian", "lv", "em", "target_informed_zero_init", "uniform", details, make_target_details(name),
+                       dict(train_steps=2, train_batch_size=128, eval_batch_size=1024), optim_details=dict(lr=1e-3), n_steps=16)
+    assert isinstance(model.target, LogisticRegression) and model.target.dim == d and model.target.data_type == name
+    res = model.evaluate()
+    assert res.samples.shape == (1024, d) and torch.isfinite(res.samples).all() and torch.isfinite(res.weights).all()
+    assert math.isfinite(res.log_norm_const_preds["log_norm_const_is"])
+    m = model.step(0)
+    assert math.isfinite(m["train/loss"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ionosphere", "credit"])
+def test_logreg_design_matrix_through_l2_matches_oracle(gpu, name):
+    """The CMCD step loop with a design matrix too large for LDS (images read through L2) against the oracle, identical seeds."""
+    from oracle import sde_oracle as orc
+    from sde_sampler_lrds_amd.distr.gauss import GaussFull
+    from sde_sampler_lrds_amd.distr.logistic_regression import LogisticRegression
+    from sde_sampler_lrds_amd.eq.sdes import ControlledLangevinSDE
+    from sde_sampler_lrds_amd.losses import oc
+    from sde_sampler_lrds_amd.experiments.baseline_configs import _score_ctrl
+    from tests import golden_cases as gc
+    X, y = _synthetic_logreg(name)
+    torch.manual_seed(5)
+    target = LogisticRegression(X_train=X, y_train=y, intercept_mean=-2.5, intercept_scale=0.5, weight_scale=4.5)
+    d = target.dim
+    A = torch.randn(d, d)
+    cov, mean = 0.01 * A @ A.T + 0.5 * torch.eye(d), 0.1 * torch.randn(d)
+    prior = GaussFull(dim=d, loc=mean, cov=cov)
+    sde = ControlledLangevinSDE(target_score=target.score, prior_score=prior.score, diff_coeff=1.0, terminal_t=1.0, clip_score=1e5)
+    ctrl = _score_ctrl(d, target)
+    for mod in (target, prior, sde, ctrl):
+        mod.to(gpu)
+    loss = oc.ControlledLangevinSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    loss.seed = 9
+    B, N = 96, 10
+    ts = torch.linspace(0.0, 1.0, N + 1, device=gpu)
+    x0 = (mean + torch.randn(B, d) @ torch.linalg.cholesky(cov).T).to(gpu)
+    x, rnd, _ = loss.simulate(ts, x0, target.unnorm_log_prob, initial_log_prob=prior.log_prob, train=False)
+    otgt = orc.LogReg(X, y, 4.5, -2.5, 0.5)
+    oprior = orc.GaussFull(mean, cov)
+    octrl = orc.Ctrl({k: v.detach().cpu() for k, v in ctrl.state_dict().items()}, "score", clip_model=1e4, target_score=otgt.score, clip_score=1e4,
+                     scale_score=1.0)
+    from oracle.baseline_oracles import PerturbedNoise
+
+    def run(noise):
+        with torch.no_grad():
+            return orc.simulate_cmcd(ts.cpu(), x0.cpu(), octrl, otgt.score, oprior.score, 1.0, 1.0, 1e5, otgt.logp, oprior.logp, noise)
+    ox, ornd, _ = run(orc.PhiloxNoise(9))
+    scale = max(1.0, float(ornd.abs().max()))
+    sens = 0.0
+    for salt in range(2):  # what the kernel's 1.2e-6 Box-Muller error does to this case (tests/test_gpu_parity.py)
+        px, prnd, _ = run(PerturbedNoise(orc.PhiloxNoise(9), salt=salt))
+        sens = max(sens, gc.rel_err(px, ox), float((prnd - ornd).abs().max()) / scale)
+    ex = gc.rel_err(x.cpu(), ox)
+    er = float((rnd.cpu().flatten() - ornd.flatten()).abs().max()) / scale
+    tol = max(1e-5, 10 * sens)
+    print(f"cmcd logreg {name} ({X.shape[0]} rows, through L2): x_N {ex:.2e}, rnd {er:.2e}  (tolerance {tol:.1e})")
+    assert ex < tol and er < tol
