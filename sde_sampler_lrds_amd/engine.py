@@ -283,11 +283,14 @@ def ref_desc(kind, utils, device, keep) -> L.Ref:
             if isinstance(var, tuple):
                 evals, evecs = var
             else:
-                key = (var.data_ptr(), var._version)
-                hit = _EIGH_CACHE.get("last")
-                if hit is None or hit[0] != key:
-                    hit = (key, torch.linalg.eigh(var.detach().double()))
-                    _EIGH_CACHE["last"] = hit
+                # cached on the owning utils dict; the entry keeps `var` itself alive, so the (address, version) key cannot be
+                # matched by another tensor that the allocator later places at the same address
+                key = (var.data_ptr(), var._version, tuple(var.shape), str(var.device))
+                hit = utils.get("_sdeng_eigh") if isinstance(utils, dict) else None
+                if hit is None or hit[0] != key or hit[2] is not var:
+                    hit = (key, torch.linalg.eigh(var.detach().double()), var)
+                    if isinstance(utils, dict):
+                        utils["_sdeng_eigh"] = hit
                 evals, evecs = hit[1][0].float(), hit[1][1].float()
             r.kind = L.REF_GMM_FULL
             r.vars_init = _dev_f32(evals, device, keep)
@@ -297,8 +300,6 @@ def ref_desc(kind, utils, device, keep) -> L.Ref:
             r.vars_init = _dev_f32(var, device, keep)
     return r
 
-
-_EIGH_CACHE = {}
 
 
 # ------------------------------------------------------------------------------------------------

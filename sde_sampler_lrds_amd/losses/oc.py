@@ -6,7 +6,8 @@ engine (csrc/) instead of a Python step loop: every step's drift-net forward, sc
 update and log-RND accumulation run inside a single persistent gfx950 kernel.
 
 What is on the HIP path: the eval / sampling direction (``change_sde_ctrl=False``), i.e. what
-``Trainable.evaluate`` times as ``eval/sample_time`` (solver/oc.py:148-158).  ``compute_eubo`` (the noising loops of
+``Trainable.evaluate`` times as ``eval/sample_time`` (solver/oc.py:148-158); ``x`` may be an ``engine.InitialDraw`` (x0 drawn by the
+kernel) and ``loss.dist`` a torch.distributed module (sharded run: global estimators and weights).  ``compute_eubo`` (the noising loops of
 SURVEY.md 8f-2) is a HIP launch too (RDS losses, DiscreteTimeReversalLossEI, CMCD on mixture targets).  The training direction (``__call__``,
 8f-1) is built for the log-variance methods (``_lv_loss``: HIP step loop + one batched autograd pass of the control); KL
 training raises instead of silently running a PyTorch loop.
@@ -91,6 +92,7 @@ class BaseOCLoss:
         self._coef_cache = {}
         self._cpu_sde = None
         self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
+        self.dist = None  # torch.distributed of a sharded run: eval() then returns global estimators and globally normalised weights
 
     # ---- reference surface -----------------------------------------------------------------
     def filter(self, rnd, samples=None):
@@ -115,8 +117,24 @@ class BaseOCLoss:
         return loss, {"train/n_filtered_cumulative": self.n_filtered}
 
     @staticmethod
-    def compute_results(rnd, compute_weights=False, ts=None, samples=None, xs=None) -> Results:
-        """losses/oc.py:134-173 on the device: one sdeng_logz call gives elbo, logsumexp, variance, weights."""
+    def compute_results(rnd, compute_weights=False, ts=None, samples=None, xs=None, dist=None) -> Results:
+        """losses/oc.py:134-173 on the device: one sdeng_logz call gives elbo, logsumexp, variance, weights.
+        ``dist`` (an initialised torch.distributed module, set as ``loss.dist`` by a sharded caller): ``rnd`` is this rank's shard;
+        the estimators and the importance weights are then those of ALL ranks' particles (one 36-byte all-gather,
+        ``parallel.global_weights``), so ``Results.weights`` concatenated over the ranks is the reference's ``softmax(-rnd, 0)``."""
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            from .. import parallel
+            if compute_weights:
+                w, res = parallel.global_weights(rnd, dist)
+            else:
+                w, res = None, parallel.global_results(rnd, dist)
+            metrics = {"eval/elbo": res["elbo"]}
+            preds = {}
+            if compute_weights:
+                preds["log_norm_const_is"] = res["log_norm_const_is"]
+                metrics["eval/lv_loss"] = res["lv_loss"]
+                metrics["eval/norm_effective_sample_size"] = res["ess"]
+            return make_results(samples=samples, weights=w, log_norm_const_preds=preds, ts=ts, xs=xs, metrics=metrics)
         stats, w = E.logz_stats(rnd, want_weights=compute_weights)
         host = stats.cpu()
         metrics = {"eval/elbo": host[0].item()}
@@ -129,8 +147,8 @@ class BaseOCLoss:
 
     def __call__(self, ts, x, *args, **kwargs):
         raise E.UnsupportedByEngine(
-            "training direction (autograd through the drift net) is not on the HIP path yet (SURVEY.md 8f-1); "
-            "this engine accelerates simulate()/eval()")
+            f"{type(self).__name__} has no training call: the subclasses implement loss(ts, x, ...) for the log-variance methods "
+            "(BaseOCLoss._lv_loss: HIP step loop + one batched autograd pass, SURVEY.md 8f-1)")
 
     def load_state_dict(self, state_dict: dict):
         self.n_filtered = state_dict["n_filtered"]
@@ -151,7 +169,8 @@ class BaseOCLoss:
             raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path "
                                         "(log-variance training is: method='lv')")
         if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
-            raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built")
+            raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built "
+                                        "(every conf/loss/*.yaml leaves both empty; listed under 'raises' in INTEGRATION.md)")
         x = self._x0(x)
         if self.traj_per_sample != 1:
             x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
@@ -198,9 +217,12 @@ class BaseOCLoss:
         return x.tensor(self.seed, self.particle0) if isinstance(x, E.InitialDraw) else x
 
     def _sde_cpu(self):
-        if self._cpu_sde is None:
-            self._cpu_sde = E._cpu_sde(self.sde)
-        return self._cpu_sde
+        """CPU copy of the SDE for the per-step scalar tables, rebuilt when a buffer of the SDE changes (load_state_dict, edits)."""
+        sig = tuple((b.data_ptr(), b._version) for b in self.sde.buffers()) if isinstance(self.sde, torch.nn.Module) else ()
+        if self._cpu_sde is None or self._cpu_sde[0] != sig:
+            self._cpu_sde = (sig, E._cpu_sde(self.sde))
+            self._coef_cache = {}
+        return self._cpu_sde[1]
 
     def _coef(self, ts, device, **kw):
         # per-step gains of the control wrapper itself (LerpCtrl: g(t) and t/T; CancelDriftCtrl: drift/g and g/2), whatever the loss
@@ -214,14 +236,26 @@ class BaseOCLoss:
             if getattr(self, "_ctrl_sde_cpu", None) is None or self._ctrl_sde_cpu[0] is not ctrl.sde:
                 self._ctrl_sde_cpu = (ctrl.sde, E._cpu_sde(ctrl.sde))
             kw["ctrl_sde"] = self._ctrl_sde_cpu[1]
+        sde_cpu = self._sde_cpu()  # (may clear the cache)
+        # the entry holds `ts` itself: while it is cached its address cannot be handed to another grid, so (address, version) is an
+        # identity -- a fresh ts per call with other values can never hit a stale table
         key = (ts.data_ptr(), ts._version, ts.numel(), str(device), tuple(sorted((k, str(v)) for k, v in kw.items())))
         hit = self._coef_cache.get(key)
-        if hit is None:
+        if hit is not None and hit[1] is ts:
+            return hit[0]
+        # another tensor object: compare by CONTENT (one small read-back) before paying for a new table
+        kwkey = key[3:]
+        ts_cpu = ts.detach().to("cpu", torch.float32)
+        for old in self._coef_cache.values():
+            if old[3] == kwkey and old[2].shape == ts_cpu.shape and torch.equal(old[2], ts_cpu):
+                hit = (old[0], ts, old[2], kwkey)
+                break
+        else:
             kw2 = dict(kw)
-            table = E.coef_table(kw2.pop("kind", self.kind), ts, self._sde_cpu(), **kw2)
-            hit = table.to(device)
-            self._coef_cache = {key: hit}
-        return hit
+            table = E.coef_table(kw2.pop("kind", self.kind), ts_cpu, sde_cpu, **kw2)
+            hit = (table.to(device), ts, ts_cpu, kwkey)
+        self._coef_cache = {key: hit}
+        return hit[0]
 
     def _terminal(self, desc, keep, device, terminal_unnorm_log_prob, reference_log_prob):
         """Fill target / ref_dist + flags; returns the callables that stay opaque (evaluated with torch after)."""
@@ -308,7 +342,9 @@ class BaseOCLoss:
 
     def _no_train(self, change_sde_ctrl):
         if change_sde_ctrl:
-            raise E.UnsupportedByEngine("change_sde_ctrl=True (log-variance training) is not on the HIP path yet (SURVEY.md 8f-1)")
+            raise E.UnsupportedByEngine("simulate(change_sde_ctrl=True) is the reference's internal training call: log-variance training "
+                                        "runs through loss(ts, x, ...) here (BaseOCLoss._lv_loss: the HIP step loop with the detached "
+                                        "control + one batched autograd pass, SURVEY.md 8f-1)")
 
 
 class EMReferenceSDELoss(BaseOCLoss):
@@ -359,7 +395,7 @@ class EMReferenceSDELoss(BaseOCLoss):
         samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
                                          reference_log_prob=reference_log_prob, change_sde_ctrl=False,
                                          return_traj=return_traj, use_ema=use_ema, noise=noise)
-        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs, dist=self.dist)
 
 
 class EIReferenceSDELoss(EMReferenceSDELoss):
@@ -386,8 +422,9 @@ class _InitialLogProbLoss(BaseOCLoss):
     """Shared eval() of the losses that start from ``initial_log_prob`` (DIS / CMCD families)."""
 
     def compute_eubo(self, *a, **k):
-        raise E.UnsupportedByEngine("compute_eubo of this loss is not on the HIP path yet (SURVEY.md 8f-2); the RDS losses' and "
-                                    "DiscreteTimeReversalLossEI's are")
+        raise E.UnsupportedByEngine("no HIP noising loop for this loss's compute_eubo (TimeReversalLoss / ExponentialIntegratorSDELoss; the "
+                                    "reference switches EUBO off for PIS and DDS too, solver/oc.py:356,436); the RDS losses', "
+                                    "DiscreteTimeReversalLossEI's and ControlledLangevinSDELoss's are HIP launches")
 
     def eval(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, compute_weights=True, return_traj=True,
              use_ema=True, *, noise=None) -> Results:
@@ -395,7 +432,7 @@ class _InitialLogProbLoss(BaseOCLoss):
         samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
                                          initial_log_prob=initial_log_prob, train=False, return_traj=return_traj,
                                          use_ema=use_ema, noise=noise, **kw)
-        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs, dist=self.dist)
 
 
 class ControlledLangevinSDELoss(_InitialLogProbLoss):
@@ -605,4 +642,4 @@ class ExponentialIntegratorSDELoss(BaseOCLoss):
         samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
                                          reference_log_prob=reference_log_prob, compute_ito_int=compute_weights,
                                          change_sde_ctrl=False, return_traj=return_traj, use_ema=use_ema, noise=noise)
-        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs, dist=self.dist)

@@ -12,6 +12,29 @@ import math
 import torch
 
 
+# Layout of the 8-float statistics vector sdeng_logz writes (include/sdeng.h) -- the ONE definition the kernel's consumers share:
+# engine.logz_stats produces it, combine_stats / global_weights consume it, tests/test_gpu_units.py checks the kernel against
+# stats_reference() index by index, and the 2-rank gloo test runs this module's own gather / combine code on it.
+ELBO, LOGZ, VAR, ESS, MAX, SUM_EXP, SUM_EXP2, SUM = range(8)
+N_STATS = 8
+
+
+def stats_reference(rnd: torch.Tensor) -> torch.Tensor:
+    """What sdeng_logz writes for one shard of log-weights ``rnd`` [B,1], restated with torch in fp64 (CPU or GPU).  Not used by the
+    product path (``engine.logz_stats`` is): it pins the layout in tests and lets the gloo test run without a GPU."""
+    v = -rnd.double().reshape(-1)
+    n = v.numel()
+    mx = v.max()
+    e = torch.exp(v - mx)
+    out = torch.empty(N_STATS, dtype=torch.float64)
+    out[ELBO] = v.mean()
+    out[LOGZ] = mx + e.sum().log() - math.log(n)
+    out[VAR] = rnd.double().var() if n > 1 else 0.0
+    out[ESS] = e.sum() ** 2 / (e ** 2).sum() / n
+    out[MAX], out[SUM_EXP], out[SUM_EXP2], out[SUM] = mx, e.sum(), (e ** 2).sum(), v.sum()
+    return out.float()
+
+
 def shard_bounds(total: int, world: int, rank: int) -> tuple[int, int]:
     """Contiguous particle range [lo, hi) of ``rank`` (first ``total % world`` ranks get one extra)."""
     base, extra = divmod(total, world)
@@ -25,14 +48,14 @@ def combine_stats(stats: torch.Tensor, counts: torch.Tensor) -> dict:
     [:,7] = sum(-rnd)."""
     stats, counts = stats.double().cpu(), counts.double().cpu()
     n = counts.sum()
-    gmax = stats[:, 4].max()
-    shift = torch.exp(stats[:, 4] - gmax)
-    se = (stats[:, 5] * shift).sum()
-    se2 = (stats[:, 6] * shift ** 2).sum()
-    total = stats[:, 7].sum()
+    gmax = stats[:, MAX].max()
+    shift = torch.exp(stats[:, MAX] - gmax)
+    se = (stats[:, SUM_EXP] * shift).sum()
+    se2 = (stats[:, SUM_EXP2] * shift ** 2).sum()
+    total = stats[:, SUM].sum()
     mean = total / n
-    local_mean = stats[:, 7] / counts
-    m2 = (stats[:, 2] * (counts - 1).clamp(min=0)).sum() + (counts * (local_mean - mean) ** 2).sum()
+    local_mean = stats[:, SUM] / counts
+    m2 = (stats[:, VAR] * (counts - 1).clamp(min=0)).sum() + (counts * (local_mean - mean) ** 2).sum()
     return {
         "elbo": float(mean),
         "log_norm_const_is": float(gmax + torch.log(se) - math.log(float(n))),
@@ -54,22 +77,38 @@ class PendingResults:
         return combine_stats(g[:, :8], g[:, 8])
 
 
-def global_results_async(rnd: torch.Tensor, dist=None) -> PendingResults:
-    """Enqueue the estimators over ALL ranks' particles from this rank's ``rnd`` shard [B,1] (device tensor)."""
-    from . import engine
-    stats, _ = engine.logz_stats(rnd, want_weights=False)
+def _local_stats(rnd, stats_fn):
+    if stats_fn is None:
+        from . import engine
+        return engine.logz_stats(rnd, want_weights=False)[0]
+    return stats_fn(rnd).to(rnd.device)
+
+
+def global_results_async(rnd: torch.Tensor, dist=None, stats_fn=None) -> PendingResults:
+    """Enqueue the estimators over ALL ranks' particles from this rank's ``rnd`` shard [B,1] (device tensor).
+    ``stats_fn`` replaces the HIP reduction (``engine.logz_stats``) -- the CPU tests pass ``stats_reference``."""
+    stats = _local_stats(rnd, stats_fn)
     # torch.full, not torch.tensor([...], device=...): a host->device copy of pageable memory synchronises the stream and
     # would stop the caller from keeping several passes in flight
     count = torch.full((1,), float(rnd.shape[0]), dtype=stats.dtype, device=rnd.device)
     payload = torch.cat([stats, count])
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return PendingResults(payload.view(1, 9))
+        return PendingResults(payload.view(1, N_STATS + 1))
     world = dist.get_world_size()
-    gathered = torch.empty(world * 9, dtype=payload.dtype, device=payload.device)
+    gathered = torch.empty(world * (N_STATS + 1), dtype=payload.dtype, device=payload.device)
     dist.all_gather_into_tensor(gathered, payload)
-    return PendingResults(gathered.view(world, 9))
+    return PendingResults(gathered.view(world, N_STATS + 1))
 
 
-def global_results(rnd: torch.Tensor, dist=None) -> dict:
+def global_results(rnd: torch.Tensor, dist=None, stats_fn=None) -> dict:
     """Estimators over ALL ranks' particles from this rank's ``rnd`` shard [B,1] (device tensor)."""
-    return global_results_async(rnd, dist).result()
+    return global_results_async(rnd, dist, stats_fn).result()
+
+
+def global_weights(rnd: torch.Tensor, dist=None, stats_fn=None):
+    """This rank's shard of ``Results.weights = softmax(-rnd, 0)`` (losses/oc.py:150-161) normalised over ALL ranks' particles:
+    w_i = exp(-rnd_i - M) / S with M, S the global maximum and exponential sum from the same 36-byte all-gather.  Returns
+    (weights [B_local, 1], global estimators dict); summed over the ranks the weights give 1."""
+    res = global_results(rnd, dist, stats_fn)
+    w = torch.exp((-rnd.double() - res["max_neg_rnd"])) / res["sum_exp"]
+    return w.to(rnd.dtype).view(-1, 1), res

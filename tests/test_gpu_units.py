@@ -87,3 +87,21 @@ def test_logz_kernel_matches_oracle(gpu):
     bad = torch.tensor([[1.0], [float("inf")], [2.0]])
     stats, _ = E.logz_stats(bad.to(gpu))
     assert not math.isfinite(stats[0].item())
+
+
+@pytest.mark.gpu
+def test_logz_layout_contract(gpu):
+    """sdeng_logz's 8 statistics, index by index, against parallel.stats_reference -- the function the 2-rank gloo test feeds through
+    the product's gather / combine code (tests/test_parallel_cpu.py): the kernel and the multi-GPU combine agree on one layout."""
+    from sde_sampler_lrds_amd import parallel
+    g = torch.Generator().manual_seed(11)
+    for B in (3, 1000, 65537):
+        rnd = 2.0 * torch.randn(B, 1, generator=g) + 30.0
+        got = E.logz_stats(rnd.to(gpu), want_weights=False)[0].cpu().double()
+        want = parallel.stats_reference(rnd).double()
+        for i, name in enumerate(("ELBO", "LOGZ", "VAR", "ESS", "MAX", "SUM_EXP", "SUM_EXP2", "SUM")):
+            assert getattr(parallel, name) == i
+            assert abs(got[i] - want[i]) <= 2e-4 * max(1.0, abs(float(want[i]))), (name, B, float(got[i]), float(want[i]))
+        # sharded weights (one rank here): global_weights == softmax(-rnd)
+        w, res = parallel.global_weights(rnd.to(gpu))
+        assert gc.rel_err(w.cpu(), torch.softmax(-rnd.double(), 0).float()) < 1e-5 and abs(float(w.double().sum()) - 1.0) < 1e-5

@@ -311,3 +311,25 @@ def test_reference_objects_compile_to_descriptors():
     res = E.resolve_logp(target.unnorm_log_prob)
     assert res is not None and E.dist_desc(res[0], "cpu", keep).kind == L.DIST_GMM_DIAG
     assert E.dist_desc(prior, "cpu", keep).kind == L.DIST_ISO_GAUSS
+
+
+def test_coef_cache_is_keyed_by_content_not_address():
+    """a fresh ``ts`` per call with other values must never hit a stale table, whatever address it lands on; the same values
+    in a new tensor reuse the table; a changed SDE buffer rebuilds it."""
+    c = gc.load("rds_ei_gmm_d8_k4")
+    loss = bc.build(c, "cpu")["loss"]
+    ts1 = torch.linspace(0.0, 1.0, 9)
+    t1 = loss._coef(ts1, "cpu", with_ref=True)
+    assert loss._coef(ts1, "cpu", with_ref=True) is t1                      # same object: identity hit
+    assert loss._coef(ts1.clone(), "cpu", with_ref=True) is t1              # same values, new tensor: content hit
+    ts2 = torch.linspace(0.0, 1.0, 9) ** 2                                  # same length, other grid
+    t2 = loss._coef(ts2, "cpu", with_ref=True)
+    assert not torch.equal(t1, t2)
+    del ts2
+    ts3 = torch.linspace(0.0, 0.5, 9)                                       # may land on ts2's address
+    assert not torch.equal(loss._coef(ts3, "cpu", with_ref=True), t2)
+    before = loss._coef(ts1, "cpu", with_ref=True).clone()
+    with torch.no_grad():
+        loss.sde.diff_coeff_sq_max.mul_(2.0)                                # e.g. load_state_dict of another VP
+    after = loss._coef(ts1, "cpu", with_ref=True)
+    assert not torch.equal(before, after)

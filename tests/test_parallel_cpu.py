@@ -1,5 +1,7 @@
-"""N>1 path on CPU: two gloo ranks shard a particle batch, exchange the 8-float partial statistics and must
-reproduce the single-process estimators of BaseOCLoss.compute_results (oracle formulas)."""
+"""N>1 path on CPU: two gloo ranks shard a particle batch, exchange the 8-float partial statistics through the product's own
+gather / combine code (parallel.py) and must reproduce the single-process estimators and importance weights of
+BaseOCLoss.compute_results (oracle formulas).  The per-shard reduction is parallel.stats_reference -- the torch restatement the HIP
+kernel sdeng_logz is checked against index by index on the GPU (tests/test_gpu_units.py::test_logz_layout_contract)."""
 import os
 import socket
 
@@ -10,16 +12,6 @@ import torch.multiprocessing as mp
 
 from oracle import sde_oracle as orc
 from sde_sampler_lrds_amd import parallel
-
-
-def local_stats(rnd):
-    """What sdeng_logz writes for one shard (include/sdeng.h), in torch (test helper)."""
-    v = -rnd.double().view(-1)
-    mx = v.max()
-    e = torch.exp(v - mx)
-    var = rnd.double().var() if v.numel() > 1 else torch.tensor(0.0)
-    return torch.tensor([v.mean(), mx + e.sum().log() - torch.log(torch.tensor(float(v.numel()))), var,
-                         e.sum() ** 2 / (e ** 2).sum() / v.numel(), mx, e.sum(), (e ** 2).sum(), v.sum()], dtype=torch.float32)
 
 
 def _free_port():
@@ -36,10 +28,13 @@ def _worker(rank, world, port, total, q):
     g = torch.Generator().manual_seed(0)
     rnd_all = 3.0 * torch.randn(total, 1, generator=g) + 5.0  # every rank can rebuild the global batch
     lo, hi = parallel.shard_bounds(total, world, rank)
-    payload = torch.cat([local_stats(rnd_all[lo:hi]), torch.tensor([float(hi - lo)])])
-    gathered = torch.empty(world * 9)
-    dist.all_gather_into_tensor(gathered, payload)
-    res = parallel.combine_stats(gathered.view(world, 9)[:, :8], gathered.view(world, 9)[:, 8])
+    # the product's own gather / combine code (parallel.global_weights -> global_results_async -> combine_stats); only the per-shard
+    # reduction is swapped for its torch restatement (the HIP kernel is checked against that same function on the GPU)
+    w, res = parallel.global_weights(rnd_all[lo:hi], dist, stats_fn=parallel.stats_reference)
+    wsum = w.double().sum().view(1)
+    dist.all_reduce(wsum)
+    res["weights_sum_over_ranks"] = float(wsum)
+    res["w_first"] = float(w[0]) if rank == 0 else None
     if rank == 0:
         q.put(res)
     dist.barrier()
@@ -66,6 +61,9 @@ def test_two_rank_sharded_estimators_match_single_process(total):
     assert abs(res["lv_loss"] - ref["lv_loss"]) < 1e-4
     assert abs(res["ess"] - ref["ess"]) < 1e-6
     assert res["n"] == total
+    # Results.weights normalised over ALL ranks (losses/oc.py:150-161): the shards' weights sum to one, entries match the softmax
+    assert abs(res["weights_sum_over_ranks"] - 1.0) < 1e-6
+    assert abs(res["w_first"] - float(torch.softmax(-rnd_all.double(), 0)[0])) < 1e-9
 
 
 def test_shard_bounds_cover_batch():
@@ -76,3 +74,19 @@ def test_shard_bounds_cover_batch():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_stats_layout_constants_match_header():
+    """include/sdeng.h documents stats[0..7]; parallel.py names the indices once for every consumer."""
+    import os
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdeng.h")).read()
+    doc = dict(re.findall(r"stats\[(\d)\] = ([^\n]*?)(?=\s{2,}|\n)", header))
+    assert "elbo" in doc[str(parallel.ELBO)] and "logsumexp" in doc[str(parallel.LOGZ)] and "var(" in doc[str(parallel.VAR)]
+    assert "max(-rnd)" in doc[str(parallel.MAX)] and "sum exp(-rnd - max)" in doc[str(parallel.SUM_EXP)]
+    assert "sum exp(2" in doc[str(parallel.SUM_EXP2)] and "sum(-rnd)" in doc[str(parallel.SUM)]
+    r = torch.tensor([[0.5], [1.5], [-0.25]])
+    s = parallel.stats_reference(r)
+    assert abs(float(s[parallel.SUM]) + float(r.sum())) < 1e-6 and abs(float(s[parallel.MAX]) - 0.25) < 1e-7
+    one = parallel.combine_stats(s.view(1, -1), torch.tensor([3.0]))
+    assert abs(one["log_norm_const_is"] - float(s[parallel.LOGZ])) < 1e-6 and abs(one["ess"] - float(s[parallel.ESS])) < 1e-6
