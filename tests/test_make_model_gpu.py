@@ -218,3 +218,74 @@ def test_logreg_design_matrix_through_l2_matches_oracle(gpu, name):
     tol = max(1e-5, 10 * sens)
     print(f"cmcd logreg {name} ({X.shape[0]} rows, through L2): x_N {ex:.2e}, rnd {er:.2e}  (tolerance {tol:.1e})")
     assert ex < tol and er < tol
+
+
+# ---- SURVEY 8f-4 on the HIP path: the reference's own sampler output, with the HIP kernels as the density ----------------------
+class _CpuGenerator:
+    """Draw every random number of the samplers from torch's CPU generator (the one the fixtures were generated with) and move it to
+    the chains' device: same seed, same consumption order -> the reference's random numbers, on GPU tensors."""
+
+    def __enter__(self):
+        self.saved = {n: getattr(torch, n) for n in ("randn", "rand", "randn_like", "rand_like", "multinomial")}
+        s = self.saved
+
+        def shaped(fn):
+            def wrap(*size, device=None, dtype=None, generator=None, **kw):
+                return fn(*size, dtype=dtype, **kw).to(device or "cpu")
+            return wrap
+        torch.randn, torch.rand = shaped(s["randn"]), shaped(s["rand"])
+        torch.randn_like = lambda t, **kw: s["randn"](t.shape, dtype=t.dtype).to(t.device)
+        torch.rand_like = lambda t, **kw: s["rand"](t.shape, dtype=t.dtype).to(t.device)
+        torch.multinomial = lambda w, n, replacement=False, **kw: s["multinomial"](w.cpu(), n, replacement=replacement).to(w.device)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.saved.items():
+            setattr(torch, n, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", __import__("tests.golden_cases", fromlist=["x"]).SAMPLER_CASES)
+def test_annealed_samplers_on_hip_densities_match_reference_fixture(gpu, name):
+    """additions/ebm_mle.py smc_sampler / re_sampler (MALA / ULA, preconditioned, PDDS) run on the GPU with
+    ``hip_tempered_log_prob_and_grads`` -- log-densities and scores from ``sdeng_dist_eval`` -- as the annealing path, against the
+    output of the reference's own samplers (tests/golden/smc_*.npz, re_*.npz): same inputs, same random numbers.  The fixtures' path
+    is N(0, 9 I)^(1-t) (N(+2, .3 I) + N(-2, .3 I))^t in unnormalised form; the HIP densities are normalised, which shifts every level's
+    log-density by a constant -- acceptance ratios, importance weights and swap ratios do not see it."""
+    from sde_sampler_lrds_amd.additions import ebm_mle
+    from sde_sampler_lrds_amd.distr.gauss import GMM, IsotropicGauss
+    from tests import golden_cases as gc
+    c = gc.load(name)
+    m = c.meta
+    d = m["d"]
+    target = GMM(dim=d, loc=torch.stack([2.0 * torch.ones(d), -2.0 * torch.ones(d)]), scale=math.sqrt(0.3) * torch.ones(2, d),
+                 mixture_weights=torch.ones(2)).to(gpu)
+    prior = IsotropicGauss(dim=d, scale=3.0).to(gpu)
+    hip = ebm_mle.hip_tempered_log_prob_and_grads(target, prior)
+    fn = (lambda t, x: hip(1.0 - t, x)) if m.get("pdds") else hip
+    # the path itself: HIP vs the fixtures' closed form (up to the per-level constant)
+    xq, tq = 2.5 * torch.randn(300, d), torch.rand(300, 1)
+    lp_h, g_h = hip(tq.to(gpu), xq.to(gpu))
+    lp_c, g_c = gc.tempered_log_prob_and_grads(tq, xq)
+    const = (1 - tq[:, 0]) * (-0.5 * d * math.log(2 * math.pi * 9.0)) + tq[:, 0] * (math.log(0.5) - 0.5 * d * math.log(2 * math.pi * 0.3))
+    # (gradient: between the modes the two component terms, each ~ m / v = 6.7, cancel -- 1e-5 of THOSE is the resolution of either formula)
+    assert gc.rel_err(lp_h.cpu(), lp_c + const) < 1e-5 and float((g_h.cpu() - g_c).abs().max()) < 1e-5 * (2.0 / 0.3) * 2
+    x_init, times, steps = gc.sampler_inputs(m)
+    kw = dict(m["kw"], **{k: v.to(gpu) for k, v in gc.sampler_precond(m).items()})
+    if m.get("pdds"):
+        from sde_sampler_lrds_amd.eq.sdes import VP
+        kw.update(use_pdds_weights=True, sde=VP(0.1, 10.0, 1.0, terminal_t=1.0).to(gpu))
+    torch.manual_seed(m["seed"])
+    with _CpuGenerator():
+        if m["sampler"] == "smc":
+            samples, steps_out, diags = ebm_mle.smc_sampler(x_init.to(gpu), times.to(gpu), fn, m["n_warm"], m["n_steps"], steps.clone().to(gpu), **kw)
+        else:
+            samples, steps_out, diags = ebm_mle.re_sampler(x_init.to(gpu), times.to(gpu), fn, kw.pop("swap_frequency"), m["n_warm"], m["n_steps"],
+                                                           steps.clone().to(gpu), **kw)
+    assert samples.shape == c["samples"].shape
+    err = (samples.cpu() - c["samples"]).abs().amax(dim=(0, 1, 3))  # per chain
+    print(f"{name}: chains {err.numel()}, max |dx| {float(err.max()):.2e}, chains off by > 1e-4: {int((err > 1e-4).sum())}")
+    assert float(err.max()) < 1e-4
+    assert float((steps_out.reshape(m["n_levels"], m["B"], 1).cpu() - c["steps_out"]).abs().max()) < 1e-6
+    for k, v in diags.items():
+        assert float((torch.as_tensor(v).float().cpu() - c["diag_" + k]).abs().max()) < 1e-4, k
