@@ -173,6 +173,9 @@ typedef struct sdeng_ref {
   const float* vars_init;  /* [k,d]  (GMM_FULL: eigenvalues of the covariances)      */
   const float* weights;    /* [k] unnormalised (normalised like distr/gauss.py:100)   */
   const float* eigvecs;    /* [k,d,d] GMM_FULL only, else NULL                        */
+  int32_t shared_var;      /* GMM_DIAG: 1 = the caller guarantees that all k rows of vars_init are equal (the reference's default
+                              initialisation, variances_init = v * ones): mixtures with 4 < k <= 64 then run on the matrix pipe */
+  int32_t reserved;
 } sdeng_ref;
 
 /* ---- noise ---------------------------------------------------------------------------------

@@ -40,7 +40,8 @@ class Net(C.Structure):
 
 
 class Ref(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("means_init", _fp), ("vars_init", _fp), ("weights", _fp), ("eigvecs", _fp)]
+    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("means_init", _fp), ("vars_init", _fp), ("weights", _fp), ("eigvecs", _fp),
+                ("shared_var", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Desc(C.Structure):

@@ -200,6 +200,69 @@ __global__ void __launch_bounds__(256) k_ref_full_tables(RefFullArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Shared-variance mixture reference on the matrix pipe (RF_GMM_MM): noised marginal mu_k = S m_k, var = VA + S2 v (eq/sdes.py:228-229,
+// 247), centre c = mean_k mu_k.  Per step: centre / 1/var vectors, logit constants, and the two split-f16 A-operand images in the
+// (to, kb, part, lane, 8 halves) layout of k_pack_mlp:  logit image [kt component tiles][KB(NT)]: (mu_k - c) / var ;
+// mean image [NT feature tiles][KB(kt)]: mu_k - c.   grid = N blocks of 256 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ref_mm_tables(RefMMArgs a) {
+  __shared__ float cbar[128], ivs[128];
+  const int k = blockIdx.x;
+  const float S = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 9];
+  const float VA = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 10];
+  const float S2 = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 11];
+  const int KBX = sd_kb(a.NT), KBK = (a.kt + 1) / 2;
+  for (int f = threadIdx.x; f < 128; f += 256) {
+    float c = 0.0f, iv = 0.0f;
+    if (f < a.d) {
+      for (int j = 0; j < a.K; ++j) c += a.means[static_cast<size_t>(j) * a.d + f];
+      c = S * (c / static_cast<float>(a.K));
+      iv = 1.0f / (VA + S2 * a.vars[f]);
+    }
+    cbar[f] = c;
+    ivs[f] = iv;
+    if (f < a.dpad) {
+      a.centre[(static_cast<size_t>(k) * 2 + 0) * a.dpad + f] = c;
+      a.centre[(static_cast<size_t>(k) * 2 + 1) * a.dpad + f] = iv;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {  // logit constants (fp64 accumulation: once per step and component)
+    const int c = threadIdx.x;
+    float b = -INFINITY;
+    if (c < a.K) {
+      float wsum = 0.0f;
+      for (int i = 0; i < a.K; ++i) wsum += a.weights ? a.weights[i] : 1.0f;
+      double q = 0.0;
+      for (int f = 0; f < a.d; ++f) {
+        const float mu = S * a.means[static_cast<size_t>(c) * a.d + f] - cbar[f];
+        q += static_cast<double>(mu * mu) * ivs[f];
+      }
+      b = logf((a.weights ? a.weights[c] : 1.0f) / wsum) - 0.5f * static_cast<float>(q);
+    }
+    a.consts[static_cast<size_t>(k) * 64 + c] = b;
+  }
+  const int n_logit = a.kt * KBX * 1024, n_mean = a.NT * KBK * 1024;  // halves
+  _Float16* img = reinterpret_cast<_Float16*>(a.images + static_cast<size_t>(k) * ((n_logit + n_mean) / 2));
+  for (int idx = threadIdx.x; idx < n_logit + n_mean; idx += 256) {
+    const bool logit = idx < n_logit;
+    const int local = logit ? idx : idx - n_logit, KB = logit ? KBX : KBK;
+    const int j8 = local & 7, lane = (local >> 3) & 63, part = (local >> 9) & 1, blk = local >> 10;
+    const int kb = blk % KB, to = blk / KB;
+    const int o = 16 * to + (lane & 15);
+    const int i = 16 * (2 * kb + (j8 >> 2)) + 4 * (lane >> 4) + (j8 & 3);
+    const int comp = logit ? o : i, f = logit ? i : o;
+    float v = 0.0f;
+    if (comp < a.K && f < a.d) {
+      const float mu = S * a.means[static_cast<size_t>(comp) * a.d + f] - cbar[f];
+      v = logit ? mu * ivs[f] : mu;
+    }
+    const _Float16 hi = static_cast<_Float16>(v);
+    img[idx] = part == 0 ? hi : static_cast<_Float16>((v - static_cast<float>(hi)) * 2048.0f);
+  }
+}
+
 // static tables of a diagonal Gaussian / mixture: tab[c][0][f] = loc, tab[c][1][f] = 1/scale^2;
 // consts[c] = (0.5*sum log var, log w_norm, sum log scale + d*log sqrt(2pi), log-mixture-prob)
 __global__ void __launch_bounds__(128) k_dist_tables(DistTabArgs a) {
@@ -652,6 +715,10 @@ int sd_launch_ref_tables(const RefTabArgs& a, int N, hipStream_t s) {
 }
 int sd_launch_ref_full_tables(const RefFullArgs& a, int N, hipStream_t s) {
   hipLaunchKernelGGL(k_ref_full_tables, dim3(N * a.K), dim3(256), 0, s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_ref_mm_tables(const RefMMArgs& a, int N, hipStream_t s) {
+  hipLaunchKernelGGL(k_ref_mm_tables, dim3(N), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_dist_tables(const DistTabArgs& a, hipStream_t s) {

@@ -40,6 +40,17 @@ struct RefFullArgs {
   float* consts;     // [N][K][2]          (0.5 log det, log w)
 };
 
+// shared-variance mixture reference on the matrix pipe (sim_kernel.hpp RF_GMM_MM): per step the logit image [components x features],
+// the mean image [features x components] (split-f16 A operands), the centre / inverse variance vectors and the logit constants
+struct RefMMArgs {
+  int K, d, dpad, NT, kt;     // kt = ceil(K / 16) component tiles (<= 4)
+  const float* coef;
+  const float *means, *vars, *weights;  // vars: [K][d], all rows equal (row 0 is read)
+  float* images;    // [N][kt*KB(NT)*512 + NT*KB(kt)*512]
+  float* centre;    // [N][2][dpad]   centre of the noised means, 1/var (0 on pad features)
+  float* consts;    // [N][64]        b_k = log w_k - 0.5 sum_f (mu_kf - c_f)^2 / var_f ; -inf on pad components
+};
+
 struct DistTabArgs {
   int K, d, dpad;
   const float *loc, *scale, *weights;  // weights nullptr: single Gaussian
@@ -73,3 +84,4 @@ int sd_launch_terminal(const TerminalArgs& a, hipStream_t s);
 int sd_launch_logz(const float* rnd, long long B, float* stats, float* weights, float* scratch, hipStream_t s);
 int sd_launch_philox(unsigned lo, unsigned hi, int step, int n_steps, long long p0, int B, int d, unsigned stream_id, float* out, hipStream_t s);
 int sd_launch_sample_x0(const sdeng_dist& ds, unsigned lo, unsigned hi, long long p0, int B, int d, float* out, hipStream_t s);
+int sd_launch_ref_mm_tables(const RefMMArgs& a, int N, hipStream_t s);

@@ -2,6 +2,7 @@
 // carving, preparation kernels, dispatch to the simulate-kernel instantiations.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -21,7 +22,7 @@ SD_TILES(SD_DECLARE_CMCD)
 int sd_launch_logreg_images(const float* X, const float* y, int n, int dw, int NT, float* image, float* y_pad, hipStream_t s);
 int sd_launch_pack_square(const float* P, const float* loc, int d, int NT, float* out, float* loc_pad, hipStream_t s);
 
-enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4 };
+enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4, RF_GMM_MM = 5 };
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };
 
 typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
@@ -56,6 +57,12 @@ static const sim_launch_fn kLogregTable[4][2] = {SD_TILES_LOGREG(SD_TAB_LOGREG)}
 #define SD_FULL_ROW(X, DT) X(DT, 4, 0, 0) X(DT, 4, 0, 1) X(DT, 4, 0, 3)
 #define SD_DECL_FULL(DT) SD_FULL_ROW(SD_DECLARE_SIM, DT)
 SD_TILES_FULL(SD_DECL_FULL)
+// shared-variance mixture reference on the matrix pipe (REF = 5): [tiles - 1][LIN, EM]
+#define SD_MM_ROW(X, DT) X(DT, 5, 0, 0) X(DT, 5, 0, 1)
+#define SD_DECL_MM(DT) SD_MM_ROW(SD_DECLARE_SIM, DT)
+SD_TILES(SD_DECL_MM)
+#define SD_TAB_MM(DT) {SD_MM_ROW(SD_ENTRY, DT)},
+static const sim_launch_fn kMMTable[8][2] = {SD_TILES(SD_TAB_MM)};
 static const sim_launch_fn kFullTable[8][3] = {{SD_FULL_ROW(SD_ENTRY, 1)}, {SD_FULL_ROW(SD_ENTRY, 2)}, {SD_FULL_ROW(SD_ENTRY, 3)}, {SD_FULL_ROW(SD_ENTRY, 4)},
                                                {nullptr, nullptr, nullptr}, {SD_FULL_ROW(SD_ENTRY, 6)}, {nullptr, nullptr, nullptr}, {SD_FULL_ROW(SD_ENTRY, 8)}};
 #define SD_CTRL_ROW(M, DT) M(DT, 0) M(DT, 1) M(DT, 2)
@@ -103,13 +110,30 @@ static size_t dist_floats(const sdeng_dist& ds, int dpad) {
   return 0;
 }
 
+static bool use_mm(const sdeng_desc* d, int DT);
 // x_in == NULL: is x0 written to memory before the step loop (workspace or x0_out), or drawn in registers by the kernel?
 // In registers for ISO_GAUSS / GAUSS_DIAG unless the initial log-density is needed (it is evaluated from x0 in memory).
 static bool x0_materialised(const sdeng_desc* d) {
   return d->x0_dist.kind == SDENG_DIST_GAUSS_FULL || (d->flags & SDENG_FLAG_INIT_LOGP) || d->form == SDENG_FORM_CMCD ||
-         d->xs_out || d->noise_in || d->ref.kind == SDENG_REF_GMM_FULL || d->net.ctrl_kind == SDENG_CTRL_NONE;
+         d->xs_out || d->noise_in || d->ref.kind == SDENG_REF_GMM_FULL || d->net.ctrl_kind == SDENG_CTRL_NONE ||
+         use_mm(d, tiles_of(d));
 }
 static int check_x0_dist(const sdeng_desc* d);
+
+// Diagonal mixture references with 4 < K <= 64 components that share one variance vector run on the matrix pipe (RF_GMM_MM):
+// forward forms with a ClippedCtrl.  SDENG_REF_MM=0 keeps the vector path (A/B measurements).
+static bool use_mm(const sdeng_desc* d, int DT) {
+  static const bool allow = [] { const char* e = getenv("SDENG_REF_MM"); return !(e && e[0] == '0'); }();
+  if (!allow || d->ref.kind != SDENG_REF_GMM_DIAG || !d->ref.shared_var) return false;
+  const int K = d->ref.k;
+  if (K <= 4 && K * 2 * 16 * DT <= SD_REFTAB_FLOATS) return false;  // small mixtures: responsibilities in registers (RF_GMM)
+  if (K > 64) return false;
+  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED || (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM)) return false;
+  const int kt = (K + 15) / 16;
+  const int piece = std::max(kt * sd_kb(DT), DT * ((kt + 1) / 2)) * 512;  // floats of the larger image
+  const int room = (160 * 1024 - static_cast<int>(sizeof(float)) * sd_lds_weight_floats(DT)) / 2 / static_cast<int>(sizeof(float));
+  return piece <= room && piece <= sd_share_buf_floats(SD_SHARE_MAX);
+}
 
 struct Layout {
   size_t wpack, temb, stheta, ref_tab, ref_mean, ref_consts, target, ref_dist, prior, rnd_init, trash, logz, cmcd, x0, total;
@@ -126,11 +150,15 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   if (d->ref.kind == SDENG_REF_GMM_FULL) {  // precision images + noised means
     L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * K * DT * sd_kb(DT) * 512 + 256);
     L.ref_mean = o; o += align64(static_cast<size_t>(d->N) * K * dpad);
+  } else if (use_mm(d, DT)) {  // logit + mean images, centre / 1/var vectors (+ 64 logit constants per step under ref_consts)
+    const int kt = (K + 15) / 16;
+    L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * (kt * sd_kb(DT) + DT * ((kt + 1) / 2)) * 512 + 1024);
+    L.ref_mean = o; o += align64(static_cast<size_t>(d->N) * 2 * dpad);
   } else {
     L.ref_tab = o; o += align64(static_cast<size_t>(d->N) * K * 2 * dpad);
     L.ref_mean = o;
   }
-  L.ref_consts = o; o += align64(static_cast<size_t>(d->N) * K * 2 + 1);  // + the shared-variance flag
+  L.ref_consts = o; o += align64(static_cast<size_t>(d->N) * (K * 2 > 64 ? K * 2 : 64) + 1);  // + the shared-variance flag (MM: 64 per step)
   L.target = o; o += dist_floats(d->target, dpad);
   L.ref_dist = o; o += dist_floats(d->ref_dist, dpad);
   L.prior = o; o += dist_floats(d->prior, dpad);
@@ -451,7 +479,21 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     const int K = d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k;
     rf = d->ref.kind == SDENG_REF_GAUSS_DIAG ? RF_GAUSS : ((K <= 4 && K * 2 * dpad <= SD_REFTAB_FLOATS) ? RF_GMM : RF_GMM_BIG);
     if (K < 1 || !d->ref.means_init || !d->ref.vars_init) return fail(SDENG_E_INVALID, "reference: null means/vars or k < 1");
-    if (d->N > 0) {
+    if (use_mm(d, DT)) {
+      rf = RF_GMM_MM;
+      const int kt = (K + 15) / 16;
+      if (d->N > 0) {
+        RefMMArgs r;
+        r.K = K; r.d = d->d; r.dpad = dpad; r.NT = DT; r.kt = kt; r.coef = d->coef;
+        r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = d->ref.weights;
+        r.images = ws + L.ref_tab; r.centre = ws + L.ref_mean; r.consts = ws + L.ref_consts;
+        SD_HIP(sd_launch_ref_mm_tables(r, d->N, s));
+      }
+      a.ref_k = K; a.ref_kc = kt;
+      a.ref_tab = ws + L.ref_tab; a.ref_mean = ws + L.ref_mean; a.ref_consts = ws + L.ref_consts;
+      const int piece = std::max(kt * sd_kb(DT), DT * ((kt + 1) / 2)) * 512;
+      a.ref_share = (piece / 256 + SD_WAVES - 1) / SD_WAVES;
+    } else if (d->N > 0) {
       RefTabArgs r;
       r.K = K; r.d = d->d; r.dpad = dpad; r.coef = d->coef;
       r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = rf != RF_GAUSS ? d->ref.weights : nullptr;
@@ -459,7 +501,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
       r.same_var = ws + L.ref_consts + static_cast<size_t>(d->N) * K * 2;
       SD_HIP(sd_launch_ref_tables(r, d->N, s));
     }
-    a.ref_k = K;
+    if (rf != RF_GMM_MM) a.ref_k = K;
     if (rf == RF_GMM_BIG) {
       // workgroup-shared table copy: two LDS buffers of whole 1 KiB chunks behind the drift-net weights (160 KiB of
       // LDS per workgroup), each holding a piece of kc components -- the whole table when it fits, otherwise the
@@ -476,8 +518,10 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
         a.ref_kc = kc;
       }
     }
-    a.ref_tab = ws + L.ref_tab; a.ref_consts = ws + L.ref_consts;
-    a.ref_same_var = ws + L.ref_consts + static_cast<size_t>(d->N) * K * 2;
+    if (rf != RF_GMM_MM) {
+      a.ref_tab = ws + L.ref_tab; a.ref_consts = ws + L.ref_consts;
+      a.ref_same_var = ws + L.ref_consts + static_cast<size_t>(d->N) * K * 2;
+    }
     a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
   } else if (d->ref.kind == SDENG_REF_GMM_FULL) {
     const int K = d->ref.k;
@@ -547,6 +591,8 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     rc = prepare_logreg(d, L, ws, DT, a, s, &unused);
     if (rc) return rc;
     fn = kLogregTable[dt_index(DT)][d->form];
+  } else if (rf == RF_GMM_MM) {
+    fn = kMMTable[dt_index(DT)][d->form];
   } else if (rf == RF_GMM_FULL) {
     if (sc != SC_NONE) return fail(SDENG_E_UNSUPPORTED, "full-covariance reference together with a Score/LerpCtrl");
     fn = kFullTable[dt_index(DT)][d->form];

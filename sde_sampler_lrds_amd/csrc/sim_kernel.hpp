@@ -12,7 +12,7 @@
 
 #include "sim_device.hpp"
 
-enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4 };  // GMM: K <= SD_KREG (responsibilities in registers); FULL: full covariances
+enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4, RF_GMM_MM = 5 };  // GMM: K <= SD_KREG (responsibilities in registers); FULL: full covariances; MM: shared-variance mixture on the matrix pipe
 enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };  // LOGREG: no reference table slots, d <= 64 (LDS)
 
 // score part of the generative control (added to clip(net)):
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   // (one LDS-DMA copy per WORKGROUP instead of every wave streaming the table from L2).  Its 8 waves then
   // walk rounds and steps in lock-step -- one barrier per table piece, reached by every wave: a wave whose tile index is
   // past the end computes on zeros with all stores masked, so trip counts are uniform by construction.
-  const int share = (REF == RF_GMM_BIG || REF == RF_GMM_FULL) ? __builtin_amdgcn_readfirstlane(a.ref_share) : 0;
+  const int share = (REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM) ? __builtin_amdgcn_readfirstlane(a.ref_share) : 0;
   float* sh_tab = lds + sd_lds_weight_floats(NT);
   const int sh_floats = sd_share_buf_floats(share);
   // full-covariance mixtures: a component's precision image (NT*KB*512 floats) is staged in FULL_PP pieces of FULL_TO output
@@ -146,6 +146,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
         __syncthreads();
         if (a.N > 0) dma_table_shared(a.ref_tab, sh_tab, min(a.ref_kc, a.ref_k) * 2 * dpad, share, wave, lane);
       }
+    }
+    if constexpr (REF == RF_GMM_MM) {  // always workgroup-shared: piece 0 = the logit image of step 0
+      __syncthreads();
+      if (a.N > 0) dma_table_shared(a.ref_tab, sh_tab, a.ref_kc * ((NT + 1) / 2) * 512, share, wave, lane);
     }
     if constexpr (REF == RF_GMM_FULL) {  // always workgroup-shared: piece 0 of the first precision image
       __syncthreads();
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       const float* rcs = a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2;
       if constexpr (ref_lds) wait_dma();
       float resp[REF == RF_GMM ? SD_KREG : 1];
-      f32x4 rs[(REF == RF_GMM_BIG || REF == RF_GMM_FULL) ? NT : 1];
+      f32x4 rs[(REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM) ? NT : 1];
 #ifdef SD_DBG_NOREF
       if constexpr (REF == RF_GMM) { resp[0] = 1.0f; resp[1] = resp[2] = resp[3] = 0.0f; }
 #else
@@ -242,6 +246,105 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
           gmm_score_end<NT>(rs, l_run);
         } else {
           gmm_score<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, rs);
+        }
+      }
+      if constexpr (REF == RF_GMM_MM) {
+        // Diagonal mixtures whose components share one variance vector (the reference's default initialisation; then true of every
+        // noised marginal), K <= 64, on the MATRIX pipe -- score_mog (distr/gauss.py:97-107) is two GEMMs around a softmax:
+        //   logit_k = log w_k - |x - mu_k|^2_iv / 2  =  <x - c, (mu_k - c) iv> + b_k + (terms common to all k, which the softmax drops)
+        //   score   = (sum_k p_k mu_k - x) iv        =  (sum_k p_k (mu_k - c) - (x - c)) iv
+        // with c = the centre of the noised means (keeps the products at the size of the mixture's SPREAD, so the expanded square
+        // loses nothing to an offset; measured against fp64 the form is as accurate as the reference's own fp32 expression,
+        // DESIGN 4).  Per step the workgroup stages two split-f16 A-operand images through the double-buffered LDS pieces of the
+        // full-covariance path: [components x features] for the logits, [features x components] for the p-weighted mean; the logit
+        // tile (rows = components, columns = particles) IS the B operand of the second product.  ~36-96 MFMAs + ~300 vector
+        // instructions per tile-step instead of ~4.5 vector instructions per element and component.
+        constexpr int KBX = (NT + 1) / 2, KTM = 4;
+        const int kt = a.ref_kc, kbk = (kt + 1) / 2;       // live component tiles, K-blocks of the mean product
+        const float* cs = a.ref_mean + static_cast<size_t>(k) * 2 * dpad;  // [centre][1/var] of this step
+        const float* bk = a.ref_consts + static_cast<size_t>(k) * (KTM * 16);
+        const int logit_floats = kt * KBX * 512, mean_floats = NT * kbk * 512;
+        const float* img = a.ref_tab + static_cast<size_t>(k) * (logit_floats + mean_floats);
+        f16x8 ch[KBX], cl[KBX];
+        {
+          f32x4 xc[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) xc[t] = x[t] - load_tile4(cs, t, g);
+          split_tiles<NT>(xc, ch, cl);
+        }
+        // ---- piece 2k: logits ----
+        wait_dma();
+        __syncthreads();
+        dma_table_shared(img + logit_floats, sh_tab + sh_floats, mean_floats, share, wave, lane);
+        f32x4 lt[KTM];
+        {
+          const f16x8* im = reinterpret_cast<const f16x8*>(sh_tab);
+#pragma unroll
+          for (int j = 0; j < KTM; ++j) {
+            lt[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (j < kt) {  // wave-uniform
+              f32x4 acc = load_tile4(bk, j, g), mx = {0.0f, 0.0f, 0.0f, 0.0f};  // b_k (-inf on pad components)
+#pragma unroll
+              for (int kb = 0; kb < KBX; ++kb) {
+                const f16x8 ah = im[((j * KBX + kb) * 2 + 0) * 64 + lane], al = im[((j * KBX + kb) * 2 + 1) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ch[kb], acc, 0, 0, 0);
+                mx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[kb], mx, 0, 0, 0);
+                mx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[kb], mx, 0, 0, 0);
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) lt[j][r] = __builtin_fmaf(mx[r], SD_LO_INV, acc[r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one component tile at a time: hoisted, the 8 KB of A operands per tile spill
+          }
+        }
+        {  // softmax over the components of each particle: registers and tiles of this lane, then the four row groups
+          float mxv = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < KTM; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mxv = fmaxf(mxv, lt[j][r]);
+          mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
+          mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
+          float den = 0.0f;
+#pragma unroll
+          for (int j = 0; j < KTM; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              lt[j][r] = (j < kt) ? expf(lt[j][r] - mxv) : 0.0f;
+              den += lt[j][r];
+            }
+          den = group_sum(den);
+          const float inv = 1.0f / den;
+#pragma unroll
+          for (int j = 0; j < KTM; ++j) lt[j] = lt[j] * inv;
+        }
+        f16x8 ph[2], pl[2];
+        split8(lt[0], lt[1], ph[0], pl[0]);
+        split8(lt[2], lt[3], ph[1], pl[1]);
+        // ---- piece 2k + 1: p-weighted mean, score ----
+        wait_dma();
+        __syncthreads();
+        if (k + 1 < a.N)
+          dma_table_shared(img + logit_floats + mean_floats, sh_tab, logit_floats, share, wave, lane);
+        {
+          const f16x8* im = reinterpret_cast<const f16x8*>(sh_tab + sh_floats);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, mx = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+              if (kb < kbk) {  // wave-uniform
+                const f16x8 ah = im[((t * kbk + kb) * 2 + 0) * 64 + lane], al = im[((t * kbk + kb) * 2 + 1) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ph[kb], acc, 0, 0, 0);
+                mx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, pl[kb], mx, 0, 0, 0);
+                mx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ph[kb], mx, 0, 0, 0);
+              }
+            }
+            const f32x4 c = load_tile4(cs, t, g), iv = load_tile4(cs + dpad, t, g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs[t][r] = (__builtin_fmaf(mx[r], SD_LO_INV, acc[r]) - (x[t][r] - c[r])) * iv[r];
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
       if constexpr (REF == RF_GMM_FULL) {
@@ -346,7 +449,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
             else rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
           }
 #endif
-          if constexpr (REF == RF_GMM_BIG || REF == RF_GMM_FULL) rq = rs[t];
+          if constexpr (REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM) rq = rs[t];
           if constexpr (REF == RF_GAUSS) rq = gauss_score_tile<NT>(x, rtab, g, t);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -472,7 +575,7 @@ template <int NT, int REF, int SC, int FORM, int PAR, int X0 = 0>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM)) +
                            ((SC == SC_LOGREG && a.lr.in_lds) ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0) +
-                           ((REF == RF_GMM_BIG || REF == RF_GMM_FULL) ? sizeof(float) * 2 * sd_share_buf_floats(a.ref_share) : 0);
+                           ((REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM) ? sizeof(float) * 2 * sd_share_buf_floats(a.ref_share) : 0);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR, X0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
@@ -482,7 +585,7 @@ static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
 template <int NT, int REF, int SC, int FORM>
 static int launch_simulate(const SimArgs& a, int grid, hipStream_t stream) {
   if (a.x0.kind != SDENG_DIST_NONE) {  // x0 drawn in registers: sdeng_api.hip (x0_materialised) only asks for it where the twin exists
-    if constexpr (FORM != SDENG_FORM_EUBO && REF != RF_GMM_FULL) {
+    if constexpr (FORM != SDENG_FORM_EUBO && REF != RF_GMM_FULL && REF != RF_GMM_MM) {
       if (!a.noise_in && !a.xs_out) return launch_simulate_par<NT, REF, SC, FORM, 0, 1>(a, grid, stream);
     }
     return static_cast<int>(hipErrorInvalidValue);

@@ -298,6 +298,14 @@ def ref_desc(kind, utils, device, keep) -> L.Ref:
         else:
             r.kind = L.REF_GMM_DIAG
             r.vars_init = _dev_f32(var, device, keep)
+            # do all components share one variance vector?  (one read-back per parameter version; the entry keeps `var` alive)
+            key = (var.data_ptr(), var._version, tuple(var.shape), str(var.device))
+            hit = utils.get("_sdeng_shared_var") if isinstance(utils, dict) else None
+            if hit is None or hit[0] != key or hit[2] is not var:
+                hit = (key, bool(torch.equal(var, var[:1].expand_as(var))), var)
+                if isinstance(utils, dict):
+                    utils["_sdeng_shared_var"] = hit
+            r.shared_var = 1 if hit[1] else 0
     return r
 
 

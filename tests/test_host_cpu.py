@@ -32,8 +32,8 @@ def test_struct_sizes_match_header_layout():
     # sizes the C compiler produces for the same field lists (checked once with hipcc: see DESIGN.md)
     assert ctypes.sizeof(L.Dist) == 64
     assert ctypes.sizeof(L.TimeEmbed) == 104
-    assert ctypes.sizeof(L.Ref) == 40
-    assert ctypes.sizeof(L.Net) == 296 and ctypes.sizeof(L.Desc) == 728  # gcc on include/sdeng.h (ABI 3)
+    assert ctypes.sizeof(L.Ref) == 48
+    assert ctypes.sizeof(L.Net) == 296 and ctypes.sizeof(L.Desc) == 736  # gcc on include/sdeng.h (ABI 3)
 
 
 def test_workspace_bytes_and_bad_descriptors_without_gpu():
