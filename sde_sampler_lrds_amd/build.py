@@ -98,11 +98,12 @@ def _write_if_changed(path, body):
         f.write(body)
 
 
-def _digest():
+def _digest(with_sources=True):
+    """Hash of the flags and the headers (+ the .hip sources): the library stamp, or the part every object depends on."""
     h = hashlib.sha256()
     for root in (CSRC, os.path.join(PKG, "..", "include")):
         for name in sorted(os.listdir(root)):
-            if name.endswith((".hip", ".hpp", ".h")):
+            if name.endswith((".hpp", ".h") + ((".hip",) if with_sources else ())):
                 h.update(open(os.path.join(root, name), "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
@@ -118,14 +119,25 @@ def build(jobs: int | None = None, force: bool = False, verbose: bool = True) ->
     jobs = jobs or min(8, os.cpu_count() or 1)
 
     usage = {}
+    common = _digest(with_sources=False)
 
     def compile_one(src):
+        """One translation unit -> object; skipped when neither the flags, nor a header, nor this source changed."""
+        import json
         obj = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
+        key = hashlib.sha256((common + open(src).read()).encode()).hexdigest()
+        meta = obj + ".json"
+        if not force and os.path.exists(obj) and os.path.exists(meta):
+            m = json.load(open(meta))
+            if m.get("key") == key:
+                usage[os.path.basename(src)] = m["usage"]
+                return obj
         cmd = [HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         usage[os.path.basename(src)] = _resource_remarks(r.stderr)
+        json.dump({"key": key, "usage": usage[os.path.basename(src)]}, open(meta, "w"))
         return obj
 
     with ThreadPoolExecutor(max_workers=jobs) as ex:

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
         for (int r = 0; r < 4; ++r) {
           const float dbv = sqdt * z[r];
           db[t][r] = dbv;
-          x[t][r] = x[t][r] + (w_s[t][r] * gg) * dt + gg * dbv;
+          x[t][r] = __builtin_fmaf(gg, dbv, __builtin_fmaf(w_s[t][r] * gg, dt, x[t][r]));  // fused (sim_kernel.hpp, update)
         }
       }
       // cost = (b_s + b_t)/g + u_s - u_t ;  rnd += 0.5 |cost|^2 dt + <cost, db>   (losses/oc.py:737-742; subtracted at :815-818)

@@ -461,13 +461,15 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
             } else if constexpr (lin) {  // eq/sdes.py:535-538: ret = c1*x + c2*(ref + u); ret += c3*z
               float sc = uv;
               if constexpr (REF != RF_NONE) sc = rq[r] + uv;
-              x[t][r] = (c1 * xv + c2 * sc) + c3 * z[r];
+              // fused multiply-adds (round 2): one rounding per term less than the reference's separate torch ops -- within an ulp
+              // of them per step, like the drift-net products -- and two instructions fewer per element
+              x[t][r] = __builtin_fmaf(c3, z[r], __builtin_fmaf(c2, sc, c1 * xv));
               suz = __builtin_fmaf(uv, z[r], suz);
             } else {  // losses/oc.py:277-284
               const float db = z[r] * c5;
               float f = c1 * xv;
-              if constexpr (REF != RF_NONE) f = f + c3 * rq[r];
-              x[t][r] = xv + (f + c2 * uv) * c4 + c2 * db;
+              if constexpr (REF != RF_NONE) f = __builtin_fmaf(c3, rq[r], f);
+              x[t][r] = __builtin_fmaf(c2, db, __builtin_fmaf(__builtin_fmaf(c2, uv, f), c4, xv));
               suz = __builtin_fmaf(uv, db, suz);
             }
           }
