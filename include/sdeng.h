@@ -87,6 +87,12 @@ extern "C" {
 #define SDENG_FLAG_INIT_LOGP 2u    /* rnd0 = log p_prior(x0)  (losses/oc.py:695-699, 935-939, 1164-1168) */
 #define SDENG_FLAG_TERM_REF 4u     /* terminal: rnd += log p_ref(x_N)  (losses/oc.py:290, 505, 645, 1390) */
 #define SDENG_FLAG_TERM_TARGET 8u  /* terminal: rnd -= log pi~(x_N)                                 */
+#define SDENG_FLAG_SPLIT_TILES 16u /* hint for small batches (B <= 8 192 = two tiles per CU; the reference's default evaluation batch is 6 000,
+                                      conf/solver/basic_oc_base.yaml:28-30): work on every 16-particle tile with four waves (one per SIMD,
+                                      a quarter of the features each) instead of one -- ~2x lower latency when the batch cannot fill the
+                                      chip.  Same noise counters; sums are formed in another order, so results equal the default path's
+                                      to fp32 round-off, not bit for bit.  Honoured for ClippedCtrl, LIN / EM forms, no / Gaussian /
+                                      small-mixture reference, d > 64, no xs_out / noise_in; ignored otherwise. */
 
 /* ---- distributions (the distr package): log-density and score by hand-coded formulas ------------ */
 #define SDENG_DIST_NONE 0

@@ -70,6 +70,13 @@ static const sim_launch_fn kFullTable[8][3] = {{SD_FULL_ROW(SD_ENTRY, 1)}, {SD_F
 SD_TILES(SD_DECL_CTRL)
 #define SD_TAB_CTRL(DT) {SD_CTRL_ROW(SD_CENTRY, DT)},
 static const sim_launch_fn kCtrlTable[8][3] = {SD_TILES(SD_TAB_CTRL)};
+// low-latency small-batch kernels (split_kernel.hpp): [tiles - 5] for 5..8 feature tiles
+typedef int (*split_launch_fn)(const SimArgs&, int rf, hipStream_t);
+int sd_launch_split_5(const SimArgs& a, int rf, hipStream_t s);
+int sd_launch_split_6(const SimArgs& a, int rf, hipStream_t s);
+int sd_launch_split_7(const SimArgs& a, int rf, hipStream_t s);
+int sd_launch_split_8(const SimArgs& a, int rf, hipStream_t s);
+static const split_launch_fn kSplitTable[4] = {sd_launch_split_5, sd_launch_split_6, sd_launch_split_7, sd_launch_split_8};
 typedef int (*cmcd_launch_fn)(const CmcdArgs&, int grid, hipStream_t);
 #define SD_TAB_CMCD(DT) sd_launch_cmcd_##DT,
 static const cmcd_launch_fn kCmcdTable[8] = {SD_TILES(SD_TAB_CMCD)};
@@ -111,12 +118,18 @@ static size_t dist_floats(const sdeng_dist& ds, int dpad) {
 }
 
 static bool use_mm(const sdeng_desc* d, int DT);
+// SDENG_FLAG_SPLIT_TILES: is the low-latency kernel built for this call?  (The reference kind is checked where it is known.)
+static bool split_eligible(const sdeng_desc* d, int DT) {
+  return (d->flags & SDENG_FLAG_SPLIT_TILES) && d->B <= 8192 && DT >= 5 && d->net.ctrl_kind == SDENG_CTRL_CLIPPED &&
+         (d->form == SDENG_FORM_LIN || d->form == SDENG_FORM_EM) && !d->xs_out && !d->noise_in &&
+         (d->ref.kind == SDENG_REF_NONE || d->ref.kind == SDENG_REF_GAUSS_DIAG || (d->ref.kind == SDENG_REF_GMM_DIAG && d->ref.k <= 4));
+}
 // x_in == NULL: is x0 written to memory before the step loop (workspace or x0_out), or drawn in registers by the kernel?
 // In registers for ISO_GAUSS / GAUSS_DIAG unless the initial log-density is needed (it is evaluated from x0 in memory).
 static bool x0_materialised(const sdeng_desc* d) {
   return d->x0_dist.kind == SDENG_DIST_GAUSS_FULL || (d->flags & SDENG_FLAG_INIT_LOGP) || d->form == SDENG_FORM_CMCD ||
          d->xs_out || d->noise_in || d->ref.kind == SDENG_REF_GMM_FULL || d->net.ctrl_kind == SDENG_CTRL_NONE ||
-         use_mm(d, tiles_of(d));
+         use_mm(d, tiles_of(d)) || split_eligible(d, tiles_of(d));
 }
 static int check_x0_dist(const sdeng_desc* d);
 
@@ -600,7 +613,8 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     fn = kSimTable[dt_index(DT)][rf][sc][d->form];
   }
   if (d->ev_start) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s));
-  SD_HIP(fn(a, grid_for(a.ntiles), s));
+  if (split_eligible(d, DT) && (rf == RF_NONE || rf == RF_GAUSS || rf == RF_GMM)) SD_HIP(kSplitTable[DT - 5](a, rf, s));
+  else SD_HIP(fn(a, grid_for(a.ntiles), s));
   if (d->ev_stop) SD_HIP(hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s));
 
   // terminal cost

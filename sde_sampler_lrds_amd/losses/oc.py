@@ -92,6 +92,7 @@ class BaseOCLoss:
         self._coef_cache = {}
         self._cpu_sde = None
         self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
+        self.split_tiles = False  # True: small batches (<= 16 384) ask for the low-latency kernels (SDENG_FLAG_SPLIT_TILES; fp32-round-off, not bit, equal)
         self.dist = None  # torch.distributed of a sharded run: eval() then returns global estimators and globally normalised weights
 
     # ---- reference surface -----------------------------------------------------------------
@@ -305,7 +306,7 @@ class BaseOCLoss:
         keep = []
         desc = L.Desc()
         desc.form = form
-        desc.flags = flags
+        desc.flags = flags | (L.FLAG_SPLIT_TILES if self.split_tiles and x.shape[0] <= 16384 else 0)
         desc.N = ts.numel() - 1
         desc.seed = int(self.seed)
         desc.particle0 = int(self.particle0)

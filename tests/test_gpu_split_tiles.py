@@ -1,0 +1,113 @@
+"""The low-latency small-batch kernels (SDENG_FLAG_SPLIT_TILES, csrc/split_kernel.hpp): a 16-particle tile worked on by four waves.
+
+Checked against the oracle ('identical seeds': the split kernel draws the standard kernel's Philox normals) and against the standard
+kernel on the same inputs (fp32 round-off apart: the hidden-layer and per-particle sums are formed in another order), for every
+eligible feature-tile count (5..8), the three reference kinds, both forward forms, ragged and odd tile counts."""
+import pytest
+import torch
+
+from oracle import baseline_oracles as bo
+from oracle import sde_oracle as orc
+from sde_sampler_lrds_amd.distr.gauss import ManyModes
+from sde_sampler_lrds_amd.eq.sdes import VP, ScaledBM
+from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
+from sde_sampler_lrds_amd.losses import oc
+from sde_sampler_lrds_amd.models.reparam import ClippedCtrl
+from sde_sampler_lrds_amd.reference import MarginalReference
+from tests import golden_cases as gc
+
+
+def _agree(std, spl, name):
+    """Split vs standard kernel.  Both are fp32 evaluations of the same trajectory with the same normals; particles that sit near a
+    separatrix between mixture components amplify the last-bit differences of the two summation orders (each kernel is then as far
+    from the fp64 trajectory as from the other: tools/probe_split_debug.py), so the criterion is per particle: the bulk agrees to
+    round-off, at most a few per thousand may differ by more than 1e-5, none wildly."""
+    ex = ((spl[0] - std[0]).abs() / std[0].abs().clamp(min=1.0)).amax(dim=1).cpu()
+    scale = max(1.0, float(std[1].abs().max()))
+    er = ((spl[1] - std[1]).abs().flatten() / scale).cpu()
+    frac = float(((ex > 1e-5) | (er > 1e-5)).float().mean())
+    print(f"split vs standard {name}: x_N median {float(ex.median()):.1e} max {float(ex.max()):.1e}, rnd median {float(er.median()):.1e} max {float(er.max()):.1e}, "
+          f"particles off by > 1e-5: {100 * frac:.2f} %")
+    assert float(ex.median()) < 2e-6 and float(er.median()) < 2e-6
+    assert frac <= max(5e-3, 1.5 / ex.numel()) and float(ex.max()) < 5e-2 and bool(torch.isfinite(spl[1]).all())
+
+
+def _both(loss, ts, x0, args, kw):
+    loss.split_tiles = False
+    std = loss.simulate(ts, x0, *args, **kw)
+    loss.split_tiles = True
+    spl = loss.simulate(ts, x0, *args, **kw)
+    again = loss.simulate(ts, x0, *args, **kw)
+    assert torch.equal(spl[0], again[0]) and torch.equal(spl[1], again[1]), "split kernel: rerun differs"
+    return std, spl
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,B,N", [(128, 4, 6000, 40), (128, 4, 17, 12), (100, 3, 1000, 24), (81, 2, 333, 16), (70, 4, 48, 16), (128, 1, 512, 16)])
+def test_split_kernel_mixture_reference_matches_oracle_and_standard_kernel(gpu, d, K, B, N):
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=d + K)
+    loss.seed = 13
+    std, spl = _both(loss, ts, x0, args, kw)
+    _agree(std, spl, f"d={d} K={K} B={B}")
+    # against the oracle on a block (identical seeds), tolerance as in tests/test_gpu_fullsize.py
+    p0, pb = max(0, B // 2 - 12), min(B, 24)
+    run = bo.runner("rds_gmm", info, ts)
+    base = orc.PhiloxNoise(13, particle0=p0)
+    ox, ornd, sc = run(x0[p0:p0 + pb].cpu(), base)
+    sens = 0.0
+    for salt in range(2):
+        px, prnd, _ = run(x0[p0:p0 + pb].cpu(), bo.PerturbedNoise(base, salt=salt))
+        sens = max(sens, gc.rel_err(px, ox), float((prnd - ornd).abs().max()) / sc)
+    ex = gc.rel_err(spl[0][p0:p0 + pb].cpu(), ox)
+    er = float((spl[1][p0:p0 + pb].cpu().flatten() - ornd.flatten()).abs().max()) / sc
+    tol = max(1e-5, 10 * sens)
+    print(f"split vs oracle: x_N {ex:.2e}, rnd {er:.2e} (tolerance {tol:.1e})")
+    assert ex < tol and er < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,cls", [("gaussian", "ei"), ("gaussian", "em"), ("none", "em"), ("gmm", "em"), ("gaussian", "ddpm")])
+def test_split_kernel_other_references_and_forms(gpu, kind, cls):
+    """Gaussian reference (RF_GAUSS), no reference (PIS-style EM with a ClippedCtrl), EM / DDPM-like forms: split vs standard kernel."""
+    torch.manual_seed(3)
+    d, B, N = 96, 700, 20
+    target = ManyModes(n_modes=3, dim=d, var=0.5, seed_loc=1, n_reference_samples=10)
+    ctrl = ClippedCtrl(base_model=cfgs._net(d), clip_model=1e4)
+    if kind == "none":
+        sde = ScaledBM(diff_coeff=0.4, terminal_t=2.0)
+        ref, refd = None, None
+    else:
+        sde = VP(0.1, 10.0, 1.0, terminal_t=1.0)
+        if kind == "gaussian":
+            ref = MarginalReference(sde, "gaussian", x_init=0.3 * torch.randn(d), var_init=0.5 + torch.rand(d))
+        else:
+            ref = MarginalReference(sde, "gmm", means_init=target.loc.clone(), variances_init=0.3 + torch.rand(3, d), weights_init=torch.tensor([1.0, 2.0, 3.0]))
+    mods = [m for m in (sde, target, ctrl, ref) if m is not None]
+    for m in mods:
+        m.to(gpu)
+    lcls = {"ei": oc.EIReferenceSDELoss, "em": oc.EMReferenceSDELoss, "ddpm": oc.DDPMLikeReferenceSDELoss}[cls]
+    loss = lcls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref)
+    loss.seed = 5
+    ts = torch.linspace(0.0, float(sde.terminal_t), N + 1, device=gpu) if cls != "ddpm" else torch.linspace(1e-3, 1.0 - 1e-3, N + 1, device=gpu)
+    x0 = torch.randn(B, d, device=gpu)
+    refd = ref.reference_distr.to(gpu).log_prob if ref is not None else (lambda x: torch.zeros(x.shape[0], device=x.device))
+    std, spl = _both(loss, ts, x0, (target.unnorm_log_prob, refd), {})
+    _agree(std, spl, f"{kind}/{cls}")
+
+
+@pytest.mark.gpu
+def test_split_flag_is_ignored_where_no_kernel_exists(gpu):
+    """d <= 64, score controls, trajectories: the flag is a hint; the standard kernel runs and results are bit-identical."""
+    from tests import build_cases as bc
+    for name in ("rds_ei_gmm_d8_k4", "pis_em_phi4_d100", "dds_two_modes_d2"):
+        c = gc.load(name)
+        b = bc.build(c, gpu)
+        b["loss"].split_tiles = False
+        a = b["loss"].simulate(b["ts"], b["x0"], *b["args"], **b["kwargs"])
+        b["loss"].split_tiles = True
+        z = b["loss"].simulate(b["ts"], b["x0"], *b["args"], **b["kwargs"])
+        assert torch.equal(a[0], z[0]) and torch.equal(a[1], z[1]), name
+    loss, ts, x0, args, kw, _ = cfgs.build_rds_gmm(gpu, 256, 8)
+    loss.split_tiles = True
+    x, rnd, xs = loss.simulate(ts, x0, *args, return_traj=True)  # trajectory requested: standard PAR kernel
+    assert xs.shape == (9, 256, 128) and torch.equal(xs[-1], x)
