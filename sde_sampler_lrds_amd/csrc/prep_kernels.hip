@@ -325,29 +325,85 @@ __global__ void __launch_bounds__(128) k_dist_tables(DistTabArgs a) {
 // log-density / score of a distribution, one thread per particle (runs once per trajectory or in
 // unit tests; the in-loop scores live in the simulate kernels).
 // ------------------------------------------------------------------------------------------------
+// distr/gauss.py:217-221 -> MixtureSameFamily.log_prob: Normal.log_prob summed + log mixture, logsumexp -- over the components
+// c0, c0 + cs, ...: the running (maximum, sum) pair, (-inf, 0) when there is none
+__device__ void gmm_logp_partial(const DistEvalArgs& a, const float* x, int c0, int cs, float& m_run, float& l_run) {
+  const DistDev& ds = a.ds;
+  m_run = -INFINITY;
+  l_run = 0.0f;
+  for (int c = c0; c < ds.k; c += cs) {
+    const float* tm = ds.tab + static_cast<size_t>(c) * 2 * a.dpad;
+    const float* tv = tm + a.dpad;
+    double acc = 0.0;  // once per trajectory: accumulate the 100+ term sum in fp64 (fp32 ulp of |log p| ~ 1.5e-5)
+    for (int f = 0; f < a.d; ++f) {
+      const float dl = x[f] - tm[f];
+      acc += static_cast<double>(dl * dl) * tv[f];
+    }
+    const float part = static_cast<float>(acc);
+    float lp = (-0.5f * part) - ds.consts[4 * c + 2];
+    if (ds.kind == SDENG_DIST_GAUSS_DIAG) { m_run = lp; l_run = 1.0f; break; }
+    lp += ds.consts[4 * c + 3];
+    const float m_new = fmaxf(m_run, lp);
+    l_run = l_run * expf(m_run - m_new) + expf(lp - m_new);
+    m_run = m_new;
+  }
+}
+
+// distr/logistic_regression.py:41-61; aux0 = X [n,d-1], aux1 = y [n]; p0 = weight_scale, p1 = intercept_mean,
+// p2 = intercept_scale, p3 = threshold.  Likelihood over the data rows n0, n0 + ns, ...; the prior apart.
+__device__ float logreg_loglik_partial(const DistEvalArgs& a, const float* x, int n0, int ns) {
+  const DistDev& ds = a.ds;
+  const int dw = a.d - 1;
+  const float c = x[dw];
+  const float eps = 1.1920928955078125e-07f;
+  float ll = 0.0f;
+  for (int n = n0; n < ds.k; n += ns) {
+    const float* Xn = ds.aux0 + static_cast<size_t>(n) * dw;
+    float lg = 0.0f;
+    for (int f = 0; f < dw; ++f) lg = __builtin_fmaf(Xn[f], x[f], lg);
+    lg += c;
+    float p = 1.0f / (1.0f + expf(-lg));
+    p = fminf(fmaxf(p, ds.p3), 1.0f - ds.p3);
+    p = fminf(fmaxf(p, eps), 1.0f - eps);
+    const float l2 = logf(p) - log1pf(-p);
+    // binary_cross_entropy_with_logits = (1-y)*l + log(1+exp(-|l|)) + max(-l,0)
+    const float y = ds.aux1[n];
+    ll -= (1.0f - y) * l2 + (fmaxf(-l2, 0.0f) + log1pf(expf(-fabsf(l2))));
+  }
+  return ll;
+}
+
+__device__ float logreg_logprior(const DistEvalArgs& a, const float* x) {
+  const DistDev& ds = a.ds;
+  const int dw = a.d - 1;
+  float prior = 0.0f;
+  const float lws = logf(ds.p0), two_ws2 = 2.0f * (ds.p0 * ds.p0);
+  for (int f = 0; f < dw; ++f) prior += (-(x[f] * x[f]) / two_ws2 - lws) - 0.91893853320467274178f;
+  const float dc = x[dw] - ds.p1;
+  prior += (-(dc * dc) / (2.0f * (ds.p2 * ds.p2)) - logf(ds.p2)) - 0.91893853320467274178f;
+  return prior;
+}
+
+// |L^-1 (x - mu)|^2 over the rows i0, i0 + is, ... of L^-1 (aux0 = loc [d], aux1 = L^-1 [d,d], lower triangular)
+__device__ float gauss_full_m2_partial(const DistEvalArgs& a, const float* x, int i0, int is) {
+  const DistDev& ds = a.ds;
+  float m2 = 0.0f;
+  for (int i = i0; i < a.d; i += is) {
+    float yi = 0.0f;
+    const float* Li = ds.aux1 + static_cast<size_t>(i) * a.d;
+    for (int j = 0; j <= i; ++j) yi = __builtin_fmaf(Li[j], x[j] - ds.aux0[j], yi);
+    m2 = __builtin_fmaf(yi, yi, m2);
+  }
+  return m2;
+}
+
 __device__ float dist_logp_row(const DistEvalArgs& a, const float* x) {
   const int d = a.d;
   const DistDev& ds = a.ds;
   float out = 0.0f;
   if (ds.kind == SDENG_DIST_GMM_DIAG || ds.kind == SDENG_DIST_GAUSS_DIAG) {
-    // distr/gauss.py:217-221 -> MixtureSameFamily.log_prob: Normal.log_prob summed + log mixture, logsumexp
-    float m_run = -INFINITY, l_run = 0.0f;
-    for (int c = 0; c < ds.k; ++c) {
-      const float* tm = ds.tab + static_cast<size_t>(c) * 2 * a.dpad;
-      const float* tv = tm + a.dpad;
-      double acc = 0.0;  // once per trajectory: accumulate the 100+ term sum in fp64 (fp32 ulp of |log p| ~ 1.5e-5)
-      for (int f = 0; f < d; ++f) {
-        const float dl = x[f] - tm[f];
-        acc += static_cast<double>(dl * dl) * tv[f];
-      }
-      const float part = static_cast<float>(acc);
-      float lp = (-0.5f * part) - ds.consts[4 * c + 2];
-      if (ds.kind == SDENG_DIST_GAUSS_DIAG) { m_run = lp; l_run = 1.0f; break; }
-      lp += ds.consts[4 * c + 3];
-      const float m_new = fmaxf(m_run, lp);
-      l_run = l_run * expf(m_run - m_new) + expf(lp - m_new);
-      m_run = m_new;
-    }
+    float m_run, l_run;
+    gmm_logp_partial(a, x, 0, 1, m_run, l_run);
     out = m_run + logf(l_run);
   } else if (ds.kind == SDENG_DIST_ISO_GAUSS) {
     // distr/gauss.py:757-762; p0 = loc, p1 = scale, p2 = -0.5*d*log(2 pi var) (host), p3 = var
@@ -377,40 +433,10 @@ __device__ float dist_logp_row(const DistEvalArgs& a, const float* x) {
   } else if (ds.kind == SDENG_DIST_GAUSS_FULL) {
     // distr/gauss.py:677-699 -> MultivariateNormal.log_prob: -0.5*(d log 2pi + |L^-1 (x-mu)|^2) - sum log diag L
     // aux0 = loc [d], aux1 = L^-1 [d,d] (lower), p0 = sum log diag L
-    float m2 = 0.0f;
-    for (int i = 0; i < d; ++i) {
-      float yi = 0.0f;
-      const float* Li = ds.aux1 + static_cast<size_t>(i) * d;
-      for (int j = 0; j <= i; ++j) yi = __builtin_fmaf(Li[j], x[j] - ds.aux0[j], yi);
-      m2 = __builtin_fmaf(yi, yi, m2);
-    }
+    const float m2 = gauss_full_m2_partial(a, x, 0, 1);
     out = -0.5f * (static_cast<float>(d) * 1.8378770664093453f + m2) - ds.p0;
   } else if (ds.kind == SDENG_DIST_LOGREG) {
-    // distr/logistic_regression.py:41-61; aux0 = X [n,d-1], aux1 = y [n]; p0 = weight_scale, p1 = intercept_mean,
-    // p2 = intercept_scale, p3 = threshold
-    const int dw = d - 1;
-    const float c = x[dw];
-    float prior = 0.0f;
-    const float lws = logf(ds.p0), two_ws2 = 2.0f * (ds.p0 * ds.p0);
-    for (int f = 0; f < dw; ++f) prior += (-(x[f] * x[f]) / two_ws2 - lws) - 0.91893853320467274178f;
-    const float dc = c - ds.p1;
-    prior += (-(dc * dc) / (2.0f * (ds.p2 * ds.p2)) - logf(ds.p2)) - 0.91893853320467274178f;
-    const float eps = 1.1920928955078125e-07f;
-    float ll = 0.0f;
-    for (int n = 0; n < ds.k; ++n) {
-      const float* Xn = ds.aux0 + static_cast<size_t>(n) * dw;
-      float lg = 0.0f;
-      for (int f = 0; f < dw; ++f) lg = __builtin_fmaf(Xn[f], x[f], lg);
-      lg += c;
-      float p = 1.0f / (1.0f + expf(-lg));
-      p = fminf(fmaxf(p, ds.p3), 1.0f - ds.p3);
-      p = fminf(fmaxf(p, eps), 1.0f - eps);
-      const float l2 = logf(p) - log1pf(-p);
-      // binary_cross_entropy_with_logits = (1-y)*l + log(1+exp(-|l|)) + max(-l,0)
-      const float y = ds.aux1[n];
-      ll -= (1.0f - y) * l2 + (fmaxf(-l2, 0.0f) + log1pf(expf(-fabsf(l2))));
-    }
-    out = ll + prior;
+    out = logreg_loglik_partial(a, x, 0, 1) + logreg_logprior(a, x);
   }
   else if (ds.kind == SDENG_DIST_RINGS) {
     // distr/rings.py:93-98: log MixtureSameFamily(Categorical(w), Normal(rad, scale))(r) + log Uniform(0,2pi) - log r
@@ -509,48 +535,152 @@ __device__ void dist_score_row(const DistEvalArgs& a, const float* x, float* sc)
   }
 }
 
-// One thread per particle, but the block's 64 rows are brought in with coalesced loads and parked in LDS with an
-// odd row stride (thread t then walks row t conflict-free); a thread reading its own row straight from HBM touches
-// 64 different cache lines per wave-instruction.
+// The block's 64 rows are brought in by all four waves with coalesced loads -- several per thread in flight, 16 bytes wide when the rows
+// are -- and parked in LDS with an odd row stride: thread (wave w, lane l) then walks row l conflict-free.  (A thread reading its own row
+// straight from HBM touches 64 different cache lines per wave-instruction; a one-wave block staging row after row had two loads in flight
+// per CU-slot and ran at 190 GB/s: 340 us for the 64 MB of cfg 2's x_N.)
+#define SD_EVAL_ROWS 64
+#define SD_EVAL_THREADS 256
+#define SD_EVAL_RED_FLOATS (SD_EVAL_THREADS * 2)
+
 __device__ inline const float* stage_rows(const float* x, int B, int d, float* sh) {
-  const int row0 = blockIdx.x * blockDim.x, stride = d | 1;
-  const int rows = B - row0 < static_cast<int>(blockDim.x) ? B - row0 : static_cast<int>(blockDim.x);
-  const float* src = x + static_cast<size_t>(row0) * d;
-  // row by row, the threads of the block across the features: coalesced, and no integer division per element (the flat-index form
-  // spent ~50 instructions on i / d and i % d for every float it moved: k_terminal ran at 150 GB/s)
-  for (int r = 0; r < rows; ++r)
-    for (int f = threadIdx.x; f < d; f += blockDim.x) sh[r * stride + f] = src[static_cast<size_t>(r) * d + f];
+  const int row0 = blockIdx.x * SD_EVAL_ROWS, stride = d | 1, tid = threadIdx.x;
+  const int rows = B - row0 < SD_EVAL_ROWS ? B - row0 : SD_EVAL_ROWS;
+  const float* src = x + static_cast<size_t>(row0) * d;  // rows * d contiguous floats; row0 * d * 4 bytes is a multiple of 256
+  if ((d & 3) == 0) {
+    const int d4 = d >> 2, n4 = rows * d4;
+    const float inv = 1.0f / static_cast<float>(d4);
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(src);
+    for (int base = tid; base < n4; base += 4 * SD_EVAL_THREADS) {
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i4 = base + j * SD_EVAL_THREADS;
+        v[j] = i4 < n4 ? src4[i4] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i4 = base + j * SD_EVAL_THREADS;
+        if (i4 < n4) {
+          const int r = static_cast<int>((static_cast<float>(i4) + 0.5f) * inv);  // i4 / d4: exact, the fraction is >= 0.5 / d4 away from an integer
+          float* dst = sh + r * stride + 4 * (i4 - r * d4);
+          dst[0] = v[j][0]; dst[1] = v[j][1]; dst[2] = v[j][2]; dst[3] = v[j][3];
+        }
+      }
+    }
+  } else {
+    const int n = rows * d;
+    const float inv = 1.0f / static_cast<float>(d);
+    for (int base = tid; base < n; base += 8 * SD_EVAL_THREADS) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = base + j * SD_EVAL_THREADS;
+        v[j] = i < n ? src[i] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = base + j * SD_EVAL_THREADS;
+        if (i < n) {
+          const int r = static_cast<int>((static_cast<float>(i) + 0.5f) * inv);
+          sh[r * stride + (i - r * d)] = v[j];
+        }
+      }
+    }
+  }
   __syncthreads();
-  return sh + threadIdx.x * stride;
+  return sh + (tid & 63) * stride;
 }
 
-__global__ void k_dist_eval(DistEvalArgs a) {
+// log-density of the block's staged rows: thread (wave w, lane l) works on row l.  The components of a mixture and the data rows of the
+// logistic-regression likelihood are dealt over the four waves and merged through LDS; every other kind is one pass over the features by
+// wave 0.  The value is returned in wave 0.  Every thread of the block calls it (barriers inside).
+__device__ float dist_logp_block(const DistEvalArgs& a, const float* x, float* red) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int NW = SD_EVAL_THREADS / 64;
+  const DistDev& ds = a.ds;
+  if (ds.kind == SDENG_DIST_GMM_DIAG && ds.k > 1) {
+    float m_run, l_run;
+    gmm_logp_partial(a, x, w, NW, m_run, l_run);
+    red[2 * threadIdx.x] = m_run;
+    red[2 * threadIdx.x + 1] = l_run;
+    __syncthreads();
+    float out = 0.0f;
+    if (w == 0) {  // wave 0 holds component 0: its running maximum is finite
+      for (int j = 1; j < NW; ++j) {
+        const float mj = red[2 * (64 * j + lane)], lj = red[2 * (64 * j + lane) + 1];
+        const float m_new = fmaxf(m_run, mj);
+        l_run = l_run * expf(m_run - m_new) + lj * expf(mj - m_new);
+        m_run = m_new;
+      }
+      out = m_run + logf(l_run);
+      if (ds.clip > 0.0f) out = clampf(out, ds.clip);
+    }
+    __syncthreads();
+    return out;
+  }
+  if (ds.kind == SDENG_DIST_LOGREG) {
+    const float ll = logreg_loglik_partial(a, x, w, NW);
+    red[threadIdx.x] = ll;
+    __syncthreads();
+    float out = 0.0f;
+    if (w == 0) {
+      float sum = ll;
+      for (int j = 1; j < NW; ++j) sum += red[64 * j + lane];
+      out = sum + logreg_logprior(a, x);
+      if (ds.clip > 0.0f) out = clampf(out, ds.clip);
+    }
+    __syncthreads();
+    return out;
+  }
+  if (ds.kind == SDENG_DIST_GAUSS_FULL) {
+    const float m2 = gauss_full_m2_partial(a, x, w, NW);
+    red[threadIdx.x] = m2;
+    __syncthreads();
+    float out = 0.0f;
+    if (w == 0) {
+      float sum = m2;
+      for (int j = 1; j < NW; ++j) sum += red[64 * j + lane];
+      out = -0.5f * (static_cast<float>(a.d) * 1.8378770664093453f + sum) - ds.p0;
+      if (ds.clip > 0.0f) out = clampf(out, ds.clip);
+    }
+    __syncthreads();
+    return out;
+  }
+  return w == 0 ? dist_logp_row(a, x) : 0.0f;
+}
+
+__global__ void __launch_bounds__(SD_EVAL_THREADS) k_dist_eval(DistEvalArgs a) {
   extern __shared__ float sh[];
+  float* red = sh + SD_EVAL_ROWS * (a.d | 1);
   const float* x = stage_rows(a.x, a.B, a.d, sh);
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= a.B) return;
-  if (a.logp_out) a.logp_out[row] = dist_logp_row(a, x);
-  if (a.score_out) dist_score_row(a, x, a.score_out + static_cast<size_t>(row) * a.d);
+  const int row = blockIdx.x * SD_EVAL_ROWS + (threadIdx.x & 63);
+  const bool writer = threadIdx.x < 64 && row < a.B;
+  if (a.logp_out) {
+    const float lp = dist_logp_block(a, x, red);
+    if (writer) a.logp_out[row] = lp;
+  }
+  if (a.score_out && writer) dist_score_row(a, x, a.score_out + static_cast<size_t>(row) * a.d);
 }
 
 // terminal cost, in place on rnd (losses/oc.py:290: rnd += ref_logp(x) - target_logp(x); :973: rnd -= target_logp(x))
-__global__ void k_terminal(TerminalArgs a) {
+__global__ void __launch_bounds__(SD_EVAL_THREADS) k_terminal(TerminalArgs a) {
   extern __shared__ float sh[];
+  float* red = sh + SD_EVAL_ROWS * (a.d | 1);
   const float* x = stage_rows(a.x, a.B, a.d, sh);
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= a.B) return;
+  const int row = blockIdx.x * SD_EVAL_ROWS + (threadIdx.x & 63);
   float term = 0.0f;
   if (a.use_ref) {
     DistEvalArgs e;
     e.ds = a.ref; e.B = a.B; e.d = a.d; e.dpad = a.dpad;
-    term = dist_logp_row(e, x);
+    term = dist_logp_block(e, x, red);
   }
   if (a.use_target) {
     DistEvalArgs e;
     e.ds = a.target; e.B = a.B; e.d = a.d; e.dpad = a.dpad;
-    term = term - dist_logp_row(e, x);
+    term = term - dist_logp_block(e, x, red);
   }
-  a.rnd[row] += term;
+  if (threadIdx.x < 64 && row < a.B) a.rnd[row] += term;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -729,11 +859,11 @@ int sd_launch_dist_tables(const DistTabArgs& a, hipStream_t s) {
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_dist_eval(const DistEvalArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_dist_eval, dim3((a.B + 63) / 64), dim3(64), 64 * (a.d | 1) * sizeof(float), s, a);
+  hipLaunchKernelGGL(k_dist_eval, dim3((a.B + SD_EVAL_ROWS - 1) / SD_EVAL_ROWS), dim3(SD_EVAL_THREADS), (SD_EVAL_ROWS * (a.d | 1) + SD_EVAL_RED_FLOATS) * sizeof(float), s, a);
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_terminal(const TerminalArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_terminal, dim3((a.B + 63) / 64), dim3(64), 64 * (a.d | 1) * sizeof(float), s, a);
+  hipLaunchKernelGGL(k_terminal, dim3((a.B + SD_EVAL_ROWS - 1) / SD_EVAL_ROWS), dim3(SD_EVAL_THREADS), (SD_EVAL_ROWS * (a.d | 1) + SD_EVAL_RED_FLOATS) * sizeof(float), s, a);
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_logz(const float* rnd, long long B, float* stats, float* weights, float* scratch, hipStream_t s) {
