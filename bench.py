@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense FP32 MFMA = packed-fp32 vector peak (256 FLOP/clk/CU)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/F16 MFMA ~2.5 PF dense
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 # Issue cost per instruction on one SIMD with two resident waves, ns (tools/ubench/valu_cost.hip, profiles/r01_ubench_valu_cost.log:
 # the "2w" column / 2).  MFMA and vector instructions of the waves of a SIMD do not overlap on gfx950
@@ -128,6 +129,13 @@ def roofline(cfg, info, B, N, k_ms, extra_flops=0):
                   "int32 mul": c["SQ_INSTS_VALU_INT32"], "convert": c["SQ_INSTS_VALU_CVT"], "mfma 16x16x32 f16": c["SQ_INSTS_MFMA"]}
         counts["other vector (logic, select, move, cross-lane)"] = max(0.0, c["SQ_INSTS_VALU"] - sum(counts.values()))
         model_ms = sum(counts[k] * ISSUE_NS[k] for k in counts) / N_SIMD * 1e-6
+        issued = c["SQ_INSTS_MFMA"] * 16384.0 / (k_ms * 1e-3) / 1e12  # one v_mfma_f32_16x16x32_f16 = 2 * 16 * 16 * 32 FLOP
+        r["mfma_pipe"] = {"issued_tflops_f16": issued, "peak": PEAK_F16_MFMA_TFLOPS, "frac": issued / PEAK_F16_MFMA_TFLOPS,
+                          "reading": "what the matrix pipe itself executes (split products included) against the dense f16 MFMA peak: the "
+                                     "pipe idles most of the time because the vector instructions of the same SIMD (noise, activations, "
+                                     "operand splits, reference score) issue in the same slots.  `frac` above can pass 1 (cfg 4, whose likelihood "
+                                     "adds two GEMMs per step): three f16 products cost 3/16 of one fp32 MFMA, so the fp32-equivalent rate "
+                                     "is an accounting figure, not a ceiling of this pipe."}
         r["issue"] = {"bound": "vector + matrix instruction issue per SIMD (they do not overlap on gfx950)",
                       "instr_per_tile_step": {k: v / tile_steps for k, v in counts.items()},
                       "vector_instr_per_tile_step": c["SQ_INSTS_VALU"] / tile_steps, "issue_cost_ns": ISSUE_NS,
