@@ -335,7 +335,7 @@ __device__ void gmm_logp_partial(const DistEvalArgs& a, const float* x, int c0, 
     const float* tm = ds.tab + static_cast<size_t>(c) * 2 * a.dpad;
     const float* tv = tm + a.dpad;
     double acc = 0.0;  // once per trajectory: accumulate the 100+ term sum in fp64 (fp32 ulp of |log p| ~ 1.5e-5)
-    for (int f = 0; f < a.d; ++f) {
+    for (int f = 0; f < a.d; ++f) {  // (fetching the wave-uniform table entries 16 at a time was measured: 2x slower, 82 registers)
       const float dl = x[f] - tm[f];
       acc += static_cast<double>(dl * dl) * tv[f];
     }
@@ -801,28 +801,41 @@ __global__ void k_sample_x0(X0Dev q, unsigned seed_lo, unsigned seed_hi, long lo
   for (int e = 0; e < 4; ++e)
     if (4 * jb + e < d) out[static_cast<size_t>(row) * d + 4 * jb + e] = x[e];
 }
+#define SD_X0_FULL_ROWS 64
 __global__ void __launch_bounds__(256) k_sample_x0_full(const float* loc, const float* L, unsigned seed_lo, unsigned seed_hi, long long particle0,
                                                        int B, int d, float* out) {
-  __shared__ float z[16][132];
-  const int row0 = blockIdx.x * 16, nj = (d + 3) / 4;
-  for (int i = threadIdx.x; i < 16 * nj; i += 256) {
-    const int r = i / nj, jb = i % nj;
+  // 64 particles per block: their normals z[r][j] and the transposed factor Lt[j][f] (odd stride) in LDS, so that the lanes of a wave
+  // -- consecutive features f of one or two particles -- read consecutive words of Lt and broadcast z; L itself is read once per
+  // block, coalesced (a lane walking its own row of L in global memory touched 64 cache lines per load).
+  extern __shared__ float sh[];
+  const int nj = (d + 3) / 4, zs = 4 * nj + 1, ls = d | 1;
+  float* z = sh;                             // [64][zs]
+  float* Lt = sh + SD_X0_FULL_ROWS * zs;     // [d][ls]
+  const int row0 = blockIdx.x * SD_X0_FULL_ROWS;
+  for (int i = threadIdx.x; i < d * d; i += 256) {
+    const int f = i / d, j = i - f * d;
+    Lt[j * ls + f] = L[i];
+  }
+  for (int i = threadIdx.x; i < SD_X0_FULL_ROWS * nj; i += 256) {
+    const int r = i / nj, jb = i - r * nj;
     const f32x4 v = philox_normal4(static_cast<uint32_t>(particle0 + row0 + r), 0u, static_cast<uint32_t>(jb), SD_X0_STREAM, seed_lo, seed_hi);
-    for (int e = 0; e < 4; ++e) z[r][4 * jb + e] = v[e];
+    for (int e = 0; e < 4; ++e) z[r * zs + 4 * jb + e] = v[e];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 16 * d; i += 256) {
-    const int r = i / d, f = i % d;
-    if (row0 + r >= B) continue;
-    const float* Lf = L + static_cast<size_t>(f) * d;
+  const int rows = B - row0 < SD_X0_FULL_ROWS ? B - row0 : SD_X0_FULL_ROWS;
+  for (int i = threadIdx.x; i < rows * d; i += 256) {
+    const int r = i / d, f = i - r * d;
     float acc = 0.0f;
-    for (int j = 0; j <= f; ++j) acc = __builtin_fmaf(Lf[j], z[r][j], acc);
-    out[static_cast<size_t>(row0 + r) * d + f] = loc[f] + acc;
+    for (int j = 0; j <= f; ++j) acc = __builtin_fmaf(Lt[j * ls + f], z[r * zs + j], acc);
+    out[static_cast<size_t>(row0) * d + i] = loc[f] + acc;
   }
 }
 int sd_launch_sample_x0(const sdeng_dist& ds, unsigned lo, unsigned hi, long long p0, int B, int d, float* out, hipStream_t s) {
   if (ds.kind == SDENG_DIST_GAUSS_FULL) {
-    hipLaunchKernelGGL(k_sample_x0_full, dim3((B + 15) / 16), dim3(256), 0, s, ds.loc, ds.aux, lo, hi, p0, B, d, out);
+    const size_t lds = (static_cast<size_t>(SD_X0_FULL_ROWS) * (4 * ((d + 3) / 4) + 1) + static_cast<size_t>(d) * (d | 1)) * sizeof(float);
+    if (lds > 160 * 1024) return static_cast<int>(hipErrorInvalidValue);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_x0_full), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(k_sample_x0_full, dim3((B + SD_X0_FULL_ROWS - 1) / SD_X0_FULL_ROWS), dim3(256), lds, s, ds.loc, ds.aux, lo, hi, p0, B, d, out);
   } else {
     X0Dev q;
     q.kind = ds.kind; q.loc = ds.loc; q.scale = ds.scale; q.p0 = ds.p0; q.p1 = ds.p1; q.out = nullptr;
