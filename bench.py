@@ -2,10 +2,10 @@
 """Benchmark of the hot path: particle-steps/sec of one whole ``simulate`` (+ log-Z estimators), and log-Z abs-err vs the reference.
 
 Headline workload (BASELINE.json configs[1]): ManyModes d=128 (K=4), RDS with a diagonal-GMM reference, VP(0.1,10),
-exponential integrator, 65 536 particles x 256 steps per GPU, FourierMLP drift net; x0 and the step noise are drawn in the kernel
-(Philox, keyed by the global particle index).  A "step" of this bench = one full pass: all 256 SDE steps of the batch, terminal cost,
-and the log-Z / ESS reduction (the window the reference times as eval/sample_time, solver/oc.py:148-158); nothing is read from HBM but
-the model (x0 is drawn in registers).
+exponential integrator, 65 536 particles x 256 steps per GPU, FourierMLP drift net; x0 and the step noise are drawn by the engine
+(Philox, keyed by the global particle index; x0 by a sampler kernel inside the timed pass, the noise in the step loop's registers).  A "step" of this bench = one full pass: all 256 SDE steps of the batch, terminal cost,
+and the log-Z / ESS reduction (the window the reference times as eval/sample_time, solver/oc.py:148-158); the inputs are the
+seed and the model.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -283,7 +283,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ManyModes d=128 K={a.modes}, RDS gmm-ref, VP(0.1,10), EI integrator, "
-                                   f"{B} particles x {N} steps per GPU, FourierMLP(4x64) drift, x0 and noise drawn in-kernel (Philox)",
+                                   f"{B} particles x {N} steps per GPU, FourierMLP(4x64) drift, x0 and noise drawn by the engine (Philox)",
                        "particles_per_gpu": B, "sde_steps": N, "parallelism": f"particle-sharded x{world}"},
             "log_z_abs_err": e["log_z_abs_err"], "parity": e["parity"], "path": e["path"],
             "log_norm_const_is": e["log_norm_const_is"], "ess": e["ess"], "spinup_s": a.spinup, "roofline": e["roofline"],

@@ -197,9 +197,8 @@ typedef struct sdeng_ref {
  *     ISO_GAUSS   x0 = p0 + p1 * z                IsotropicGauss.sample   distr/gauss.py:772-787 (no truncation)
  *     GAUSS_DIAG  x0 = loc + scale * z            Gauss.sample distr/gauss.py:235-239;  scale == NULL: x0 = loc  (Delta.sample, distr/delta.py:27-31)
  *     GAUSS_FULL  x0 = loc + L z  (L = aux)       GaussFull.sample        distr/gauss.py:709-713 (MultivariateNormal)
- *   ISO_GAUSS / GAUSS_DIAG are drawn in registers by the step-loop kernel itself (x0 never touches HBM) in the plain sampling
- *   call -- forward form, no FLAG_INIT_LOGP, no xs_out / noise_in, diagonal or no reference; otherwise x0 is first materialised in
- *   the workspace (same values).  x0_out (optional, [B,d]) receives the drawn x0 either way.
+ *   A sampler kernel writes x0 into the workspace -- or into x0_out ([B,d], optional) -- ahead of the step loop: one launch,
+ *   0.2 % of a cfg-2 pass.  (A step-loop variant that drew x0 in registers was measured 1-4 % slower and dropped)
  */
 typedef struct sdeng_desc {
   int32_t abi_version;   /* SDENG_ABI_VERSION                                              */

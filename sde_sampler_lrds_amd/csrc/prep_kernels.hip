@@ -838,7 +838,7 @@ int sd_launch_sample_x0(const sdeng_dist& ds, unsigned lo, unsigned hi, long lon
     hipLaunchKernelGGL(k_sample_x0_full, dim3((B + SD_X0_FULL_ROWS - 1) / SD_X0_FULL_ROWS), dim3(256), lds, s, ds.loc, ds.aux, lo, hi, p0, B, d, out);
   } else {
     X0Dev q;
-    q.kind = ds.kind; q.loc = ds.loc; q.scale = ds.scale; q.p0 = ds.p0; q.p1 = ds.p1; q.out = nullptr;
+    q.kind = ds.kind; q.loc = ds.loc; q.scale = ds.scale; q.p0 = ds.p0; q.p1 = ds.p1;
     const long long n = static_cast<long long>(B) * ((d + 3) / 4);
     hipLaunchKernelGGL(k_sample_x0, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, q, lo, hi, p0, B, d, out);
   }

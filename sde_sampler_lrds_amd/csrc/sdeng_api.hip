@@ -124,13 +124,6 @@ static bool split_eligible(const sdeng_desc* d, int DT) {
          (d->form == SDENG_FORM_LIN || d->form == SDENG_FORM_EM) && !d->xs_out && !d->noise_in &&
          (d->ref.kind == SDENG_REF_NONE || d->ref.kind == SDENG_REF_GAUSS_DIAG || (d->ref.kind == SDENG_REF_GMM_DIAG && d->ref.k <= 4));
 }
-// x_in == NULL: is x0 written to memory before the step loop (workspace or x0_out), or drawn in registers by the kernel?
-// In registers for ISO_GAUSS / GAUSS_DIAG unless the initial log-density is needed (it is evaluated from x0 in memory).
-static bool x0_materialised(const sdeng_desc* d) {
-  return d->x0_dist.kind == SDENG_DIST_GAUSS_FULL || (d->flags & SDENG_FLAG_INIT_LOGP) || d->form == SDENG_FORM_CMCD ||
-         d->xs_out || d->noise_in || d->ref.kind == SDENG_REF_GMM_FULL || d->net.ctrl_kind == SDENG_CTRL_NONE ||
-         use_mm(d, tiles_of(d)) || split_eligible(d, tiles_of(d));
-}
 static int check_x0_dist(const sdeng_desc* d);
 
 // Diagonal mixture references with 4 < K <= 64 components that share one variance vector run on the matrix pipe (RF_GMM_MM):
@@ -187,7 +180,7 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
     if (d->form == SDENG_FORM_CMCD || d->form == SDENG_FORM_CMCD_EUBO) o += align64(DT * sd_kb(DT) * 512) + align64(16 * DT);
   }
   L.x0 = o;
-  if (!d->x_in && x0_materialised(d)) o += align64(static_cast<size_t>(d->B) * d->d);
+  if (!d->x_in && !d->x0_out) o += align64(static_cast<size_t>(d->B) * d->d);  // the engine's own x0 draw
   L.total = o;
   return true;
 }
@@ -465,17 +458,17 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   a.xs_out = d->xs_out; a.noise_in = d->noise_in;
   a.trash = ws + L.trash;
   a.ntiles = (d->B + 15) / 16;
-  sdeng_desc dm;  // x0 drawn by the engine and needed in memory: materialise it, then run as if the caller had passed it
-  if (!d->x_in && x0_materialised(d)) {
+  // x0 drawn by the engine: k_sample_x0 writes it (workspace, or the caller's x0_out), then everything runs as if the caller had passed
+  // it.  A twin of the step-loop kernel that drew x0 in registers was built and dropped: same instruction count, but its loop came out
+  // of the register allocator 4 % slower on cfg 2 and 1.3 % on cfg 3 (profiles/r02_x0_draw_ab.log); the sampler kernel costs 0.2 %.
+  sdeng_desc dm;
+  if (!d->x_in) {
     float* x0 = d->x0_out ? d->x0_out : ws + L.x0;
     SD_HIP(sd_launch_sample_x0(d->x0_dist, a.seed_lo, a.seed_hi, d->particle0, d->B, d->d, x0, s));
     dm = *d;
     dm.x_in = x0;
     d = &dm;
     a.x_in = x0;
-  } else if (!d->x_in) {
-    a.x0.kind = d->x0_dist.kind; a.x0.loc = d->x0_dist.loc; a.x0.scale = d->x0_dist.scale;
-    a.x0.p0 = d->x0_dist.p0; a.x0.p1 = d->x0_dist.p1; a.x0.out = d->x0_out;
   }
 
   if (d->form == SDENG_FORM_CMCD || d->form == SDENG_FORM_CMCD_EUBO) return simulate_cmcd(d, L, ws, DT, a, s);

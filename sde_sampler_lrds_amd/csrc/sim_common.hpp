@@ -76,13 +76,12 @@ struct LogregDev {
   int in_lds;               // 1: the two images fit behind the drift-net weights in LDS; 0: the kernel reads them through L2
 };
 
-// initial particles drawn by the engine (sdeng_desc.x_in == NULL): x0 = loc + scale * z, z = Philox stream 1 at step 0
+// initial particles drawn by the engine (k_sample_x0; sdeng_desc.x_in == NULL): x0 = loc + scale * z, z = Philox stream 1 at step 0
 struct X0Dev {
-  int kind;            // SDENG_DIST_NONE: x0 is read from x_in; ISO_GAUSS / GAUSS_DIAG: drawn in registers
+  int kind;            // ISO_GAUSS / GAUSS_DIAG
   const float* loc;    // GAUSS_DIAG [d]
   const float* scale;  // GAUSS_DIAG [d], or nullptr: x0 = loc (Delta)
   float p0, p1;        // ISO_GAUSS: loc, scale
-  float* out;          // optional [B,d]: the drawn x0
 };
 
 struct SimArgs {
@@ -117,5 +116,4 @@ struct SimArgs {
   float cmcd_g, cmcd_clip;
   int ntiles;             // ceil(B / 16)
   LogregDev lr;           // in-loop logistic-regression score (ScoreCtrl on a LOGREG target, CMCD)
-  X0Dev x0;               // in-register draw of the initial particles
 };

@@ -391,7 +391,7 @@ SD_INLINE f32x4 philox_normal4(uint32_t pidx, uint32_t step, uint32_t jb, uint32
 // Initial particles: prior.sample((B,)) as a pure function of (seed, global particle, feature) -- the Philox
 // normals of stream 1 at step 0.  IsotropicGauss.sample (distr/gauss.py:777): loc + scale * randn; Gauss.sample: loc + scale * z per
 // feature; Delta.sample (distr/delta.py:31): loc.  One quad = features 4 jb .. 4 jb + 3 of one particle; pads are 0.
-// The same function serves the in-register draw of the step-loop kernels and the standalone sampler (k_sample_x0).
+// Used by the sampler kernel k_sample_x0 (prep_kernels.hip), which runs ahead of the step loop when the caller passes no x0.
 // ----------------------------------------------------------------------------------------------
 #define SD_X0_STREAM 1u
 SD_INLINE f32x4 x0_quad(const X0Dev& q, uint32_t pidx, int jb, int d, uint32_t k0, uint32_t k1) {
@@ -412,19 +412,6 @@ SD_INLINE f32x4 x0_quad(const X0Dev& q, uint32_t pidx, int jb, int d, uint32_t k
   }
   return x;
 }
-template <int NT>
-SD_INLINE void draw_x0(const SimArgs& a, uint32_t pidx, int g, f32x4 (&x)[NT]) {
-  // The draw sits at the top of the persistent tile loop and nothing in it but `pidx` changes from tile to tile: left alone, the
-  // compiler hoists the loc / scale loads and the key-only part of the Philox rounds out of that loop and keeps them in registers for
-  // the whole kernel.  Re-reading the parameters through an opaque move per tile pins the work to where it is used.
-  X0Dev q = a.x0;
-  uint32_t k0 = a.seed_lo, k1 = a.seed_hi;
-  int d = a.d;
-  asm volatile("" : "+s"(q.loc), "+s"(q.scale), "+s"(q.p0), "+s"(q.p1), "+s"(k0), "+s"(k1), "+s"(d));
-#pragma unroll
-  for (int t = 0; t < NT; ++t) x[t] = x0_quad(q, pidx, 4 * t + g, d, k0, k1);
-}
-
 // ----------------------------------------------------------------------------------------------
 // Gaussian-mixture score (distr/gauss.py:97-107 score_mog).
 // tab: [K][2][dpad] (mean, 1/var); consts: [K][cstride] with [0] = 0.5*sum log var, [1] = log w_k.
@@ -720,20 +707,6 @@ SD_INLINE void store_rows(float* __restrict__ dst, float* __restrict__ trash, ui
 #pragma unroll
   for (int t = 0; t < NT; ++t) store_quad(dst, trash, row, d, live, t, g, v[t]);
 }
-// x0 of a tile: read from x_in (X0 = 0), or drawn in registers and optionally written to x0_out (X0 = 1).  The draw is a
-// template parameter of the step-loop kernel, not a run-time branch: with both paths in one kernel the register allocator paid for the
-// draw's prologue peak in every instantiation (+30-40 VGPRs, scratch in 87 of them) -- so only the forward, no-trajectory kernels
-// have an X0 = 1 twin, and everything else gets its drawn x0 from memory (sdeng_api.hip x0_materialised).
-template <int NT, int X0>
-SD_INLINE void initial_state(const SimArgs& a, uint32_t row, uint32_t pidx, bool live, int g, float* trash, f32x4 (&x)[NT]) {
-  if constexpr (X0 == 0) {
-    load_rows<NT>(a.x_in, row, a.d, live, g, x);
-  } else {
-    draw_x0<NT>(a, pidx, g, x);
-    if (a.x0.out) store_rows<NT>(a.x0.out, trash, row, a.d, live, g, x);
-  }
-}
-
 // ----------------------------------------------------------------------------------------------
 // CMCD building blocks (eq/sdes.py:101-110, distr/logistic_regression.py, distr/gauss.py:129-135)
 // ----------------------------------------------------------------------------------------------

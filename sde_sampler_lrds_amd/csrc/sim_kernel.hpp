@@ -64,8 +64,7 @@ SD_INLINE void add_ctrl_score_tile(const SimArgs& a, f32x4& u, const f32x4& sv, 
 }
 
 // PAR = 1 adds the parity-mode paths (injected noise, trajectory dump); PAR = 0 keeps them out of the step loop.
-// X0 = 1 draws the initial particles in registers (sim_device.hpp initial_state); only PAR = 0 forward kernels have that twin.
-template <int NT, int REF, int SC, int FORM, int PAR, int X0 = 0>
+template <int NT, int REF, int SC, int FORM, int PAR>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const SimArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int dpad = 16 * NT;
@@ -131,7 +130,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     const bool live = row < static_cast<uint32_t>(a.B);
     const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
     f32x4 x[NT];
-    initial_state<NT, X0>(a, row, pidx, live, g, trash, x);
+    load_rows<NT>(a.x_in, row, a.d, live, g, x);  // x0: the caller's, or the engine's own draw (k_sample_x0 ahead of this launch)
     // rnd0 = log p_prior(x0) when the loss asks for it (losses/oc.py:695-699, 935-939), from k_dist_eval
     float rnd = 0.0f;
     if (a.rnd_init) rnd = (live ? a.rnd_init[row] : 0.0f);
@@ -573,25 +572,19 @@ static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
   int sd_launch_ctrl_##NT##_##SC(const SimArgs& a, int grid, hipStream_t s) { return launch_ctrl_forward<NT, SC>(a, grid, s); }
 
 // host-side launcher, one per instantiation (defined in gen/sim_*.hip)
-template <int NT, int REF, int SC, int FORM, int PAR, int X0 = 0>
+template <int NT, int REF, int SC, int FORM, int PAR>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM)) +
                            ((SC == SC_LOGREG && a.lr.in_lds) ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0) +
                            ((REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM) ? sizeof(float) * 2 * sd_share_buf_floats(a.ref_share) : 0);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR, X0>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_simulate<NT, REF, SC, FORM, PAR, X0>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_simulate<NT, REF, SC, FORM, PAR>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
 }
 template <int NT, int REF, int SC, int FORM>
 static int launch_simulate(const SimArgs& a, int grid, hipStream_t stream) {
-  if (a.x0.kind != SDENG_DIST_NONE) {  // x0 drawn in registers: sdeng_api.hip (x0_materialised) only asks for it where the twin exists
-    if constexpr (FORM != SDENG_FORM_EUBO && REF != RF_GMM_FULL && REF != RF_GMM_MM) {
-      if (!a.noise_in && !a.xs_out) return launch_simulate_par<NT, REF, SC, FORM, 0, 1>(a, grid, stream);
-    }
-    return static_cast<int>(hipErrorInvalidValue);
-  }
   if (a.noise_in || a.xs_out) return launch_simulate_par<NT, REF, SC, FORM, 1>(a, grid, stream);
   return launch_simulate_par<NT, REF, SC, FORM, 0>(a, grid, stream);
 }

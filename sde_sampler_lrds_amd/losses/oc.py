@@ -214,7 +214,7 @@ class BaseOCLoss:
 
     def _x0(self, x):
         """``x`` as a tensor: an ``engine.InitialDraw`` (x0 left to the engine) is materialised with this loss's seed and shard
-        offset -- the same x0 the kernel would have drawn in registers."""
+        offset -- the same x0 sdeng_simulate draws itself when handed an InitialDraw."""
         return x.tensor(self.seed, self.particle0) if isinstance(x, E.InitialDraw) else x
 
     def _sde_cpu(self):

@@ -3,8 +3,8 @@
 x0 = prior.sample((B,)) is a pure function of (seed, global particle index): x0 = loc + scale * z with z the Philox normals of
 stream 1 at step 0 -- the definition the fixtures were generated with (tests/golden/gen_golden.py: x0 = philox_normal(seed, 0, 0, B, d,
 stream=1)).  Checked here: the standalone sampler against the oracle's CPU definition for every prior kind, shard independence, and
-that a simulate() which draws x0 in the kernel equals, bit for bit, the same simulate() fed the materialised x0 -- and the reference's
-fixture outputs in 'identical seeds' mode."""
+that a simulate() which leaves x0 to the engine equals, bit for bit, the same simulate() fed the x0 tensor of sdeng_sample_x0 -- and the
+reference's fixture outputs in 'identical seeds' mode."""
 import pytest
 import torch
 
@@ -57,8 +57,9 @@ def test_sample_x0_matches_oracle_definition(gpu, kind, d):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", ["rds_gmm", "pis_phi4", "cmcd_logreg"])
 def test_in_kernel_draw_equals_materialised_x0(gpu, cfg):
-    """cfg 2 (IsotropicGauss: drawn in registers), cfg 3 (Delta: x0 = loc, nothing read), cfg 4 (GaussFull + initial log-density:
-    materialised in the workspace) -- each against the same simulate() fed the x0 tensor of sdeng_sample_x0, sharded too."""
+    """cfg 2 (IsotropicGauss), cfg 3 (Delta: x0 = loc), cfg 4 (GaussFull + initial log-density): x0 drawn by the engine inside
+    sdeng_simulate (sampler kernel ahead of the step loop) -- each against the same simulate() fed the x0 tensor of sdeng_sample_x0,
+    sharded too."""
     B, N = 5000, 12
     if cfg == "rds_gmm":
         loss, ts, _, args, kw, info = cfgs.build_rds_gmm(gpu, B, N)
@@ -76,7 +77,7 @@ def test_in_kernel_draw_equals_materialised_x0(gpu, cfg):
         assert float(x0.abs().max()) == 0.0
     a = loss.simulate(ts, draw, *args, **kw)
     b = loss.simulate(ts, x0, *args, **kw)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "in-kernel x0 differs from the materialised x0"
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "x0 drawn inside sdeng_simulate differs from sdeng_sample_x0"
     cut = 2003
     s1 = loss.simulate(ts, E.InitialDraw(prior, cut, gpu), *args, **kw)
     loss.particle0 = cut
@@ -101,5 +102,5 @@ def test_identical_seeds_end_to_end_against_reference_fixture(gpu, name):
     x, rnd, _ = b["loss"].simulate(b["ts"], draw, *b["args"], **b["kwargs"])
     ex, ernd = gc.rel_err(x.cpu(), c["out_x"]), rnd_err(rnd, c)
     tol = philox_tol(name)
-    print(f"{name}: x0 drawn in the kernel: max rel err x_N {ex:.2e}, rnd {ernd:.2e} (tolerance {tol:.1e})")
+    print(f"{name}: x0 drawn by the engine: max rel err x_N {ex:.2e}, rnd {ernd:.2e} (tolerance {tol:.1e})")
     assert ex < tol and ernd < tol
