@@ -348,7 +348,8 @@ SD_INLINE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
     const uint64_t p1 = static_cast<uint64_t>(0xCD9E8D57u) * c2;
     const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
     const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    // three-input xor in one instruction (gfx950 v_bitop3_b32, truth table 0x96); the compiler emits two v_xor_b32 for a ^ b ^ c
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
     c0 = n0;
     c1 = lo1;
     c2 = n2;

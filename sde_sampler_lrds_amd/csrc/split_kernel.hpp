@@ -33,7 +33,9 @@ __host__ __device__ inline int sd_split_lds_bytes(int NT) { return (sd_lds_weigh
 
 template <int NT, int REF, int FORM>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(const SimArgs a) {
+#ifndef SD_EXPERIMENT_WAVES  // occupancy experiments build the other kernels with another wave count; this one is then not launched
   static_assert(SD_WAVES == 8, "two tiles of four waves per workgroup");
+#endif
   static_assert(REF == RF_NONE || REF == RF_GAUSS || REF == RF_GMM, "split kernel: no / Gaussian / small-mixture reference");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int dpad = 16 * NT, KBX = (NT + 1) / 2;
