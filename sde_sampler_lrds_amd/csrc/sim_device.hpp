@@ -363,7 +363,8 @@ SD_INLINE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
   o[3] = c3;
 }
 
-SD_INLINE float u01(uint32_t bits) { return (static_cast<float>(bits >> 9) + 0.5f) * 1.1920928955078125e-07f; }
+// (n + 0.5) * 2^-23 with n = bits >> 9 < 2^23: every step is exact in fp32, so the single fma below is the same number
+SD_INLINE float u01(uint32_t bits) { return __builtin_fmaf(static_cast<float>(bits >> 9), 1.1920928955078125e-07f, 5.9604644775390625e-08f); }
 
 // normals of features 4*jb .. 4*jb+3 of global particle `pidx` at step `step`.  Counter order
 // (pidx, jb, step, stream): the first round multiplies c0 and c2 and XORs c1 into the c2 product, so the step
