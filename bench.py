@@ -110,7 +110,7 @@ def roofline(cfg, info, B, N, k_ms, extra_flops=0):
     achieved = flops_ps * B * N / (k_ms * 1e-3) / 1e12
     r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
          "traffic": None, "kernel_ms": k_ms, "algorithmic_flops_per_particle_step": flops_ps,
-         "algorithmic_hbm_bytes_per_launch": (info["d"] + 1) * 4 * B + (0 if cfg != "cmcd_logreg" else info["d"] * 4 * B),
+         "algorithmic_hbm_bytes_per_launch": (2 * info["d"] + 1) * 4 * B,  # x0 in (written by the sampler kernel), x_N and rnd out
          "note": "peak = dense FP32 MFMA/vector rate (an equivalence: results carry fp32 accuracy; the GEMMs are issued as a 3-product "
                  "f16 split on v_mfma_f32_16x16x32_f16, 3x the algorithmic FLOP on the f16 pipe).  The binding resource is "
                  "instruction issue: see `issue`."}
