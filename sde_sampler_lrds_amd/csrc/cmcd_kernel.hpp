@@ -48,8 +48,8 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   } else {
     static_assert(TGT != CT_LOGREG || NT <= 4, "logistic regression: d <= 64 (design matrix in LDS)");
     // (two copies of the body on purpose: a pointer selected between LDS and global memory would make every A-operand read a flat load)
-    if (s.lr.in_lds) logreg_score<NT>(x, xh, xl, s.lr, s.d, lds + sd_lds_weight_floats(NT), lane, ts);
-    else logreg_score<NT>(x, xh, xl, s.lr, s.d, s.lr.image, lane, ts);
+    if (s.lr.in_lds) logreg_score<NT, true>(x, xh, xl, s.lr, s.d, lds + sd_lds_weight_floats(NT), lane, ts);
+    else logreg_score<NT, true>(x, xh, xl, s.lr, s.d, s.lr.image, lane, ts);
   }
 
   // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
@@ -202,6 +202,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     for (int k = 0; k < s.N; ++k) {
       const float* cf = s.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float dt = cf[2], sqdt = cf[3];
+      // the Philox key re-read through an opaque move every step: left alone, the compiler hoists the ten round keys (20 SGPRs) out of
+      // the step loop, runs out of scalar registers and spills them to VGPR lanes -- one v_readlane + wait states per key and use
+      uint32_t key_lo = s.seed_lo, key_hi = s.seed_hi;
+      asm volatile("" : "+s"(key_lo), "+s"(key_hi));
       // y = x + (b_s + u_s g) dt + g db ,  db = sqrt(dt) z      (losses/oc.py:722-724; :800-802 with -u for the noising loop)
       f32x4 db[NT];
 #pragma unroll
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
         if (s.noise_in) {
           z = load_quad(s.noise_in + static_cast<size_t>(k) * s.B * s.d, row, s.d, live, t, g);
         } else {
-          z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, s.seed_lo, s.seed_hi);
+          z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, key_lo, key_hi);
 #pragma unroll
           for (int r = 0; r < 4; ++r) z[r] = feat_live<NT>(t, r, 4 * g, s.d) ? z[r] : 0.0f;
         }

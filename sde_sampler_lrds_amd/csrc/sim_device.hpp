@@ -737,7 +737,8 @@ SD_INLINE float logreg_residual(float logit, float y, float p_lo, float p_hi) {
 
 // score of the logistic-regression posterior for a 16-particle tile: prior part + Xa^T (y - sigmoid(Xa w)), both
 // products on the split-f16 matrix path with the A operands read from the two LDS images at `images`.
-template <int NT>
+// PADS_ZERO: the caller keeps the pad features of x at exactly 0 (the CMCD kernel); otherwise they may hold noise and are masked here.
+template <int NT, bool PADS_ZERO = false>
 SD_INLINE void logreg_score(const f32x4 (&x)[NT], const f16x8 (&xh)[(NT + 1) / 2], const f16x8 (&xl)[(NT + 1) / 2], const LogregDev& lr,
                             int d, const float* images, int lane, f32x4 (&ts)[NT]) {
   constexpr int KB = (NT + 1) / 2;
@@ -747,15 +748,22 @@ SD_INLINE void logreg_score(const f32x4 (&x)[NT], const f16x8 (&xh)[(NT + 1) / 2
   const f16x8* im_grad = reinterpret_cast<const f16x8*>(images + sd_lr_logit_floats(NT, lr.n_rows));
   const int row_kb = sd_lr_row_kb(lr.n_rows), row_tiles = sd_lr_row_tiles(lr.n_rows);
   f32x4 tm[NT];
+  // Prior part, with as few per-feature masks as possible: only the last tile can hold pad features (NT = ceil(d / 16)) -- and in the
+  // CMCD kernel the pads of x are exactly 0 (x0 pads, masked noise, zero weight / image rows), so -x / s^2 is 0 there by itself; the
+  // intercept (feature d - 1) is patched in the one tile that holds it.  The 2 x 16 lane masks of a fully masked form are loop
+  // invariants: the compiler kept them in 64 SGPRs across the step loop, ran out of scalar registers and paid a v_readlane pair +
+  // wait states per use (110 in the cfg-4 step loop).
+  const int fi = d - 1, ti = fi >> 4, ri = fi & 15;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int f = feat(t, r, g);
-      const float xv = x[t][r];
-      float v = -xv * lr.inv_w_scale2;                                  // logistic_regression.py:72
-      v = (f == d - 1) ? -(xv - lr.c_mean) * lr.inv_c_scale2 : v;       // :74
-      ts[t][r] = (f < d) ? v : 0.0f;
+      ts[t][r] = -x[t][r] * lr.inv_w_scale2;   // logistic_regression.py:72
+      if constexpr (!PADS_ZERO) ts[t][r] = feat_live<NT>(t, r, 4 * g, d) ? ts[t][r] : 0.0f;
+    }
+    if (t == ti) {  // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ts[t][r] = (4 * g + r == ri) ? -(x[t][r] - lr.c_mean) * lr.inv_c_scale2 : ts[t][r];  // :74
     }
     tm[t] = zero;
   }
