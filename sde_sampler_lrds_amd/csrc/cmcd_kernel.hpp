@@ -155,7 +155,9 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   }
 }
 
-template <int NT, int TGT, bool EUBO>
+// PAR = 1: the twin that can replay injected noise and write the trajectory (return_traj, parity tests); the plain sampler (PAR = 0)
+// carries neither path -- their masked loads and stores cost scalar registers in the step loop even when they never run.
+template <int NT, int TGT, bool EUBO, int PAR>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(const CmcdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const SimArgs& s = a.s;
@@ -182,7 +184,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     load_rows<NT>(s.x_in, row, s.d, live, g, x);  // (x0 drawn by the engine is materialised first: the initial log-density needs it, sdeng_api.hip)
     float rnd = 0.0f;
     if (s.rnd_init) rnd = (live ? s.rnd_init[row] : 0.0f);  // rnd0 = log p_prior(x0)  (losses/oc.py:695-699)
-    if (s.xs_out) store_rows<NT>(s.xs_out, trash, row, s.d, live, g, x);
+    if constexpr (PAR != 0) {
+      if (s.xs_out) store_rows<NT>(s.xs_out, trash, row, s.d, live, g, x);
+    }
     // carried between steps: w_s = b_s/g + u_s, the only combination of (u_s, b_s) the step needs:
     //   y = x + (b_s + u_s g) dt + g db = x + g w_s dt + g db ;   cost = (b_s + b_t)/g + u_s - u_t = w_s + (b_t/g - u_t)
     // (16 registers per 64 features less than carrying u_s and b_s; identical arithmetic for g = 1, the conf default).
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         f32x4 z;
-        if (s.noise_in) {
+        if (PAR != 0 && s.noise_in) {
           z = load_quad(s.noise_in + static_cast<size_t>(k) * s.B * s.d, row, s.d, live, t, g);
         } else {
           z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, key_lo, key_hi);
@@ -251,21 +255,28 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
       cdb = group_sum(cdb);
       rnd += sgn * ((0.5f * c2) * dt);
       rnd += sgn * cdb;
-      if (s.xs_out) store_rows<NT>(s.xs_out + static_cast<size_t>(k + 1) * s.B * s.d, trash, row, s.d, live, g, x);
+      if constexpr (PAR != 0) {
+        if (s.xs_out) store_rows<NT>(s.xs_out + static_cast<size_t>(k + 1) * s.B * s.d, trash, row, s.d, live, g, x);
+      }
     }
     store_rows<NT>(s.x_out, trash, row, s.d, live, g, x);
     if (live && g == 0) s.rnd_out[row] = rnd;
   }
 }
 
-template <int NT, int TGT, bool EUBO>
-static int launch_cmcd_t(const CmcdArgs& a, int grid, hipStream_t stream) {
+template <int NT, int TGT, bool EUBO, int PAR>
+static int launch_cmcd_p(const CmcdArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(a.s.lr.in_lds ? cmcd_lds_floats(NT, a.s.lr.n_rows) : sd_lds_weight_floats(NT)) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT, TGT, EUBO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate_cmcd<NT, TGT, EUBO, PAR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_simulate_cmcd<NT, TGT, EUBO>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_simulate_cmcd<NT, TGT, EUBO, PAR>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
+}
+template <int NT, int TGT, bool EUBO>
+static int launch_cmcd_t(const CmcdArgs& a, int grid, hipStream_t stream) {
+  if (a.s.noise_in || a.s.xs_out) return launch_cmcd_p<NT, TGT, EUBO, 1>(a, grid, stream);
+  return launch_cmcd_p<NT, TGT, EUBO, 0>(a, grid, stream);
 }
 template <int NT>
 static int launch_cmcd(const CmcdArgs& a, int grid, hipStream_t stream) {
