@@ -98,29 +98,61 @@ __global__ void __launch_bounds__(64) k_time_embed(TimeEmbedArgs a) {
 // ------------------------------------------------------------------------------------------------
 // reference marginals per step (eq/sdes.py:228-229, 247): mean = s*m, var = s^2 sigma^2 + s^2 v.
 // tab[k][c][0][f] = mean, tab[k][c][1][f] = 1/var (0 on pad features); consts[k][c] = (0.5*sum log var, log w_c).
-// grid = N*K blocks of 128 threads.
+// `centred` (the step loop's K = SD_KREG shared-variance path, sim_device.hpp gmm_resp_centred) and same_var[0] != 0: instead
+// tab[k][c][0] = (mean_c - cen)/var, tab[k][0][1] = 1/var, tab[k][1][1] = cen = centre of the noised means, the other rows 0;
+// consts[k][c][1] = log w_c - 0.5 sum (mean_c - cen)^2/var.
+// grid = N*K blocks of 128 threads.  same_var[0] comes from k_same_var, launched ahead of this kernel.
 // ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_same_var(const float* vars, int K, int d, float* same_var) {
+  // do all components share one variance vector?  (bitwise: the shortcuts it enables are exact algebra)
+  int differ = 0;
+  for (int i = threadIdx.x; i < K * d; i += 128) differ |= vars[i] != vars[i % d];
+  differ = __syncthreads_or(differ);
+  if (threadIdx.x == 0) same_var[0] = differ ? 0.0f : 1.0f;
+}
+
 __global__ void __launch_bounds__(128) k_ref_tables(RefTabArgs a) {
   __shared__ float red[128];
   const int k = blockIdx.x / a.K, c = blockIdx.x % a.K;
   const float S = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 9];
   const float VA = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 10];
   const float S2 = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 11];
+  const bool centred = a.centred && a.K == SD_KREG && a.same_var[0] != 0.0f;
   float* tm = a.tab + (static_cast<size_t>(k) * a.K + c) * 2 * a.dpad;
   float* tv = tm + a.dpad;
-  float ls = 0.0f;
+  float ls = 0.0f, quad = 0.0f;
   for (int f = threadIdx.x; f < a.dpad; f += 128) {
-    float mean = 0.0f, iv = 0.0f;
+    float mean = 0.0f, iv = 0.0f, cen = 0.0f;
     if (f < a.d) {
       mean = S * a.means[static_cast<size_t>(c) * a.d + f];
       const float var = VA + S2 * a.vars[static_cast<size_t>(c) * a.d + f];
       iv = 1.0f / var;
       ls += logf(var);
+      if (centred) {
+        float sum = 0.0f;
+        for (int j = 0; j < SD_KREG; ++j) sum += a.means[static_cast<size_t>(j) * a.d + f];
+        cen = S * (sum * (1.0f / SD_KREG));
+      }
     }
-    tm[f] = mean;
-    tv[f] = iv;
+    if (centred) {
+      const float dm = mean - cen;
+      quad = __builtin_fmaf(dm * dm, iv, quad);
+      tm[f] = dm * iv;
+      tv[f] = c == 0 ? iv : (c == 1 ? cen : 0.0f);
+    } else {
+      tm[f] = mean;
+      tv[f] = iv;
+    }
   }
   red[threadIdx.x] = ls;
+  __syncthreads();
+  for (int s = 64; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float ls_sum = red[0];
+  __syncthreads();
+  red[threadIdx.x] = quad;
   __syncthreads();
   for (int s = 64; s > 0; s >>= 1) {
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
@@ -131,14 +163,8 @@ __global__ void __launch_bounds__(128) k_ref_tables(RefTabArgs a) {
     for (int i = 0; i < a.K; ++i) wsum += a.weights ? a.weights[i] : 1.0f;
     const float w = (a.weights ? a.weights[c] : 1.0f) / wsum;  // distr/gauss.py:100 (normalised in place upstream)
     float* cs = a.consts + (static_cast<size_t>(k) * a.K + c) * 2;
-    cs[0] = 0.5f * red[0];
-    cs[1] = logf(w);
-  }
-  if (blockIdx.x == 0) {  // do all components share one variance vector?  (bitwise: the shortcut it enables is exact algebra)
-    int differ = 0;
-    for (int i = threadIdx.x; i < a.K * a.d; i += 128) differ |= a.vars[i] != a.vars[i % a.d];
-    differ = __syncthreads_or(differ);
-    if (threadIdx.x == 0) a.same_var[0] = differ ? 0.0f : 1.0f;
+    cs[0] = 0.5f * ls_sum;
+    cs[1] = centred ? logf(w) - 0.5f * red[0] : logf(w);
   }
 }
 
@@ -856,6 +882,7 @@ int sd_launch_time_embed(const TimeEmbedArgs& a, int N, hipStream_t s) {
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_ref_tables(const RefTabArgs& a, int N, hipStream_t s) {
+  hipLaunchKernelGGL(k_same_var, dim3(1), dim3(128), 0, s, a.vars, a.K, a.d, a.same_var);
   hipLaunchKernelGGL(k_ref_tables, dim3(N * a.K), dim3(128), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }

@@ -28,6 +28,7 @@ struct RefTabArgs {
   float* tab;     // [N][K][2][dpad]
   float* consts;  // [N][K][2]
   float* same_var;  // [1]: 1.0 when every component has the same variance vector (then so has every noised marginal)
+  int centred;      // 1: K = SD_KREG shared-variance mixtures get the centred table of gmm_resp_centred (the standard step loop asks for it)
 };
 
 // full-covariance mixture reference (SDENG_REF_GMM_FULL): per step and component the noised precision as an MFMA image

@@ -505,6 +505,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
       r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = rf != RF_GAUSS ? d->ref.weights : nullptr;
       r.tab = ws + L.ref_tab; r.consts = ws + L.ref_consts;
       r.same_var = ws + L.ref_consts + static_cast<size_t>(d->N) * K * 2;
+      r.centred = (rf == RF_GMM && !split_eligible(d, DT)) ? 1 : 0;  // the split-tile kernel reads the plain (mean, 1/var) table
       SD_HIP(sd_launch_ref_tables(r, d->N, s));
     }
     if (rf != RF_GMM_MM) a.ref_k = K;

@@ -578,6 +578,63 @@ SD_INLINE f32x4 gmm_score_tile_shared_var(const f32x4 (&x)[NT], const float* __r
   return acc;
 }
 
+// Exactly SD_KREG components with one variance vector, centred table (k_ref_tables, `centred`): with c the centre of the noised means,
+// y = x - c and a_k = (m_k - c)/var,
+//     logit_k = b_k + <y, a_k>   (the quadratic term -0.5 sum y^2/var is common to all components and drops out of the softmax;
+//                                  b_k = log w_k - 0.5 sum (m_k - c)^2/var)
+//     score   = sum_k p_k (m_k - x)/var = sum_k p_k a_k - y/var                      (sum_k p_k = 1)
+// one fma per element and component for the logits and one for the score: 352 instead of 576 vector instructions per tile-step at
+// d = 128.  Centring keeps the magnitudes of the dot products at those of the mode separations.
+// Table rows: [k][0] = a_k, [0][1] = 1/var, [1][1] = c; consts[k][1] = b_k.
+template <int NT>
+SD_INLINE void gmm_resp_centred(const f32x4 (&x)[NT], const float* __restrict__ tab, const float* __restrict__ consts, int g,
+                                float (&p)[SD_KREG]) {
+  constexpr int dpad = 16 * NT;
+  float lp[SD_KREG];
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) lp[k] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 y = x[t] - load_tile4(tab + 3 * dpad, t, g);
+#pragma unroll
+    for (int k = 0; k < SD_KREG; ++k) {
+      const f32x4 ak = load_tile4(tab + static_cast<size_t>(k) * 2 * dpad, t, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lp[k] = __builtin_fmaf(y[r], ak[r], lp[k]);
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) {
+    lp[k] = consts[2 * k + 1] + group_sum(lp[k]);
+    mx = fmaxf(mx, lp[k]);
+  }
+  float den = 0.0f;
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) {
+    p[k] = expf(lp[k] - mx);
+    den += p[k];
+  }
+  const float inv = 1.0f / den;
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) p[k] *= inv;
+}
+template <int NT>
+SD_INLINE f32x4 gmm_score_tile_centred(const f32x4 (&x)[NT], const float* __restrict__ tab, int g, const float (&p)[SD_KREG], int t) {
+  constexpr int dpad = 16 * NT;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < SD_KREG; ++k) {
+    const f32x4 ak = load_tile4(tab + static_cast<size_t>(k) * 2 * dpad, t, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(p[k], ak[r], acc[r]);
+  }
+  const f32x4 iv = load_tile4(tab + dpad, t, g), c = load_tile4(tab + 3 * dpad, t, g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(c[r] - x[t][r], iv[r], acc[r]);
+  return acc;
+}
+
 // Gaussian (one component) score of one tile: -(x - mean)/var  (distr/gauss.py:124-126)
 template <int NT>
 SD_INLINE f32x4 gauss_score_tile(const f32x4 (&x)[NT], const float* __restrict__ tab, int g, int t) {

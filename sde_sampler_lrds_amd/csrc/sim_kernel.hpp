@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
   const bool full_d = a.d == dpad;
   float* trash = a.trash + tid * 4;
   bool same_var = false;
-  if constexpr (REF == RF_GMM) same_var = a.N > 0 && a.ref_same_var[0] != 0.0f;
+  if constexpr (REF == RF_GMM) same_var = a.N > 0 && a.ref_same_var[0] != 0.0f;  // written by k_same_var ahead of the table kernel
   const bool kfull = REF == RF_GMM && a.ref_k == SD_KREG;  // all SD_KREG components present: the unguarded instantiations
   const bool kfast = kfull && same_var;
 
@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
       if constexpr (REF == RF_GMM) { resp[0] = 1.0f; resp[1] = resp[2] = resp[3] = 0.0f; }
 #else
       if constexpr (REF == RF_GMM) {
-        if (kfull) gmm_resp<NT, SD_KREG>(x, rtab, rcs, 2, SD_KREG, a.ref_c1, g, resp);
+        if (kfast) gmm_resp_centred<NT>(x, rtab, rcs, g, resp);  // k_ref_tables wrote the centred table under the same condition
+        else if (kfull) gmm_resp<NT, SD_KREG>(x, rtab, rcs, 2, SD_KREG, a.ref_c1, g, resp);
         else gmm_resp<NT>(x, rtab, rcs, 2, a.ref_k, a.ref_c1, g, resp);
       }
 #endif
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
           if constexpr (REF == RF_GMM) rq = f32x4{resp[0], resp[0], resp[0], resp[0]};
 #else
           if constexpr (REF == RF_GMM) {
-            if (kfast) rq = gmm_score_tile_shared_var<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t);  // the reference's default reference: one test
+            if (kfast) rq = gmm_score_tile_centred<NT>(x, rtab, g, resp, t);  // the reference's default reference: one test
             else if (kfull) rq = gmm_score_tile<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t);
             else rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
           }

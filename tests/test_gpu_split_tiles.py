@@ -17,13 +17,16 @@ from sde_sampler_lrds_amd.reference import MarginalReference
 from tests import golden_cases as gc
 
 
-def _agree(std, spl, name):
+def _agree(std, spl, name, terms=()):
     """Split vs standard kernel.  Both are fp32 evaluations of the same trajectory with the same normals; particles that sit near a
     separatrix between mixture components amplify the last-bit differences of the two summation orders (each kernel is then as far
     from the fp64 trajectory as from the other: tools/probe_split_debug.py), so the criterion is per particle: the bulk agrees to
-    round-off, at most a few per thousand may differ by more than 1e-5, none wildly."""
+    round-off, at most a few per thousand may differ by more than 1e-5, none wildly.  Log-weights are judged relative to their largest
+    summand (the terminal log-densities `terms`, O(d)), like everywhere else: the two kernels evaluate a 4-mode shared-variance
+    mixture in different algebraic forms (the standard kernel's is centred, sim_device.hpp gmm_resp_centred), so their log-weights
+    differ by an ulp of that summand."""
     ex = ((spl[0] - std[0]).abs() / std[0].abs().clamp(min=1.0)).amax(dim=1).cpu()
-    scale = max(1.0, float(std[1].abs().max()))
+    scale = max([1.0, float(std[1].abs().max())] + [float(f(std[0]).abs().max()) for f in terms])
     er = ((spl[1] - std[1]).abs().flatten() / scale).cpu()
     frac = float(((ex > 1e-5) | (er > 1e-5)).float().mean())
     print(f"split vs standard {name}: x_N median {float(ex.median()):.1e} max {float(ex.max()):.1e}, rnd median {float(er.median()):.1e} max {float(er.max()):.1e}, "
@@ -48,7 +51,7 @@ def test_split_kernel_mixture_reference_matches_oracle_and_standard_kernel(gpu, 
     loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=d + K)
     loss.seed = 13
     std, spl = _both(loss, ts, x0, args, kw)
-    _agree(std, spl, f"d={d} K={K} B={B}")
+    _agree(std, spl, f"d={d} K={K} B={B}", terms=args[:2])
     # against the oracle on a block (identical seeds), tolerance as in tests/test_gpu_fullsize.py
     p0, pb = max(0, B // 2 - 12), min(B, 24)
     run = bo.runner("rds_gmm", info, ts)
@@ -92,7 +95,7 @@ def test_split_kernel_other_references_and_forms(gpu, kind, cls):
     x0 = torch.randn(B, d, device=gpu)
     refd = ref.reference_distr.to(gpu).log_prob if ref is not None else (lambda x: torch.zeros(x.shape[0], device=x.device))
     std, spl = _both(loss, ts, x0, (target.unnorm_log_prob, refd), {})
-    _agree(std, spl, f"{kind}/{cls}")
+    _agree(std, spl, f"{kind}/{cls}", terms=(target.unnorm_log_prob, refd))
 
 
 @pytest.mark.gpu
