@@ -41,7 +41,7 @@ def runner(cfg: str, info: dict, ts: torch.Tensor):
         sde = orc.VP(0.1, 10.0, 1.0, 1.0)
         tgt = orc.GMMDiag(info["target"].loc.cpu(), info["target"].scale.cpu(), info["target"].mixture_weights.cpu())
         ctrl = orc.Ctrl(_sd(info["ctrl"]), "clipped", clip_model=1e4)
-        means, var, w = info["means"].cpu(), 0.5 * torch.ones(info["K"], info["d"]), torch.ones(info["K"])
+        means, var, w = info["means"].cpu(), info["ref_var"].cpu(), info["ref_weights"].cpu()
         loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
         refd = orc.GMMDiag(loc0, v0.sqrt(), w)
 

@@ -43,7 +43,7 @@ def _flops(d):
     return 2 * (2 * 64 * d + 2 * 64 * 64)
 
 
-def build_rds_gmm(device, B, N, d=128, K=4, seed=1, x_seed=None):
+def build_rds_gmm(device, B, N, d=128, K=4, seed=1, x_seed=None, ref_var=None, ref_weights=None):
     """configs[1]: ManyModes d=128, RDS with a diagonal-GMM reference, VP(0.1, 10), exponential integrator.
     ``seed`` fixes the model (drift net, reference means); ``x_seed`` (default: ``seed``) the initial particles, so the ranks
     of a sharded run build the SAME sampler and draw different particles."""
@@ -52,14 +52,17 @@ def build_rds_gmm(device, B, N, d=128, K=4, seed=1, x_seed=None):
     target = ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
     ctrl = ClippedCtrl(base_model=_net(d), clip_model=1e4)
     means = target.loc.clone() + 0.1 * torch.randn(K, d)
-    ref = MarginalReference(sde, "gmm", means_init=means, variances_init=0.5 * torch.ones(K, d), weights_init=torch.ones(K))
+    # reference mixture: SURVEY 8d's spec (variance 0.5, equal weights) unless a test asks for other [K,d] variances / [K] weights
+    ref_var = 0.5 * torch.ones(K, d) if ref_var is None else ref_var.clone()
+    ref_weights = torch.ones(K) if ref_weights is None else ref_weights.clone()
+    ref = MarginalReference(sde, "gmm", means_init=means, variances_init=ref_var.clone(), weights_init=ref_weights.clone())
     for m in (sde, target, ctrl, ref):
         m.to(device)
     loss = oc.EIReferenceSDELoss(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref)
     ts = get_timesteps(0.0, 1.0, steps=N).to(device)
     x0 = torch.randn(B, d, generator=torch.Generator().manual_seed(seed if x_seed is None else x_seed)).to(device)
     args = (target.unnorm_log_prob, ref.reference_distr.to(device).log_prob)
-    info = dict(sde=sde, target=target, ctrl=ctrl, means=means, K=K, d=d, flops=_flops(d),
+    info = dict(sde=sde, target=target, ctrl=ctrl, means=means, ref_var=ref_var, ref_weights=ref_weights, K=K, d=d, flops=_flops(d),
                 workload=f"ManyModes d={d} K={K}, RDS gmm-ref, VP(0.1,10), EI integrator")
     return loss, ts, x0, args, {}, info
 

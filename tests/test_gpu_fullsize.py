@@ -137,6 +137,27 @@ def test_shared_mixture_table(gpu, d, K, B):
     _block_vs_oracle("rds_gmm", info, ts, x0, x, rnd, 11, f"shared table d={d} K={K} B={B}", p0=p0, pb=pb)
 
 
+# ---- four-component references: the centred shared-variance form (gmm_resp_centred) and the general form next to it -------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,B", [(128, 2048 + 5), (100, 777), (40, 300), (8, 64)])
+@pytest.mark.parametrize("kind", ["shared", "distinct", "three_shared"])
+def test_four_mode_reference_forms(gpu, d, B, kind):
+    """K = 4 with ONE variance vector (varying over the features) and unequal weights runs the centred table / one-fma logits;
+    distinct variances run the general K = 4 form; K = 3 with a shared vector the general shared-variance form.  Each against the
+    oracle on a block, identical seeds; pad features at d = 100, 40, 8."""
+    K = 3 if kind == "three_shared" else 4
+    g = torch.Generator().manual_seed(100 * d + K)
+    v = 0.3 + torch.rand(d, generator=g)
+    var = v.repeat(K, 1) if kind != "distinct" else 0.3 + torch.rand(K, d, generator=g)
+    w = torch.arange(1.0, K + 1.0)
+    N = 16
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=d + K, ref_var=var, ref_weights=w)
+    loss.seed = 17
+    x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw) if B >= 64 * 2 else loss.simulate(ts, x0, *args, **kw)
+    _block_vs_oracle("rds_gmm", info, ts, x0, x, rnd, 17, f"K={K} {kind} d={d}", p0=max(0, B // 2 - 12), pb=min(B, 24))
+    assert bool(torch.isfinite(rnd).all())
+
+
 # ---- every kernel family at full occupancy --------------------------------------------------------------------------
 # The golden cases replicated to 32 768+ particles (each replica draws its own Philox noise): reruns and shards must be
 # bit-identical, and blocks of the big run -- chosen so that every wave slot of a workgroup is covered -- must equal a
