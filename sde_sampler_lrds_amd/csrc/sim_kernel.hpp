@@ -42,6 +42,17 @@ SD_INLINE float ctrl_score_term(const SimArgs& a, float sv, float xv, float st, 
 template <int KIND, bool CLIP>
 SD_INLINE void add_ctrl_score_tile_k(const SimArgs& a, f32x4& u, const f32x4& sv, const f32x4& xv, float st, float score_gain, float lerp_w,
                                      int t, int g4, int d) {
+  if constexpr (KIND == SDENG_CTRL_SCORE) {
+    // ScoreCtrl (models/reparam.py:112-117): u += scale * clip(score) * s_theta.  The clip almost never binds (1e4): tile-level test,
+    // 4-instruction clamp only when some lane is out of range; the two gains are one per-step scalar, the add is fused -- one
+    // instruction per element instead of seven (one rounding instead of three: within an ulp of the reference's separate ops).
+    f32x4 s = sv;
+    if constexpr (CLIP) clamp_tile_rare(s, a.clip_score);
+    const float gain = a.scale_score * st;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = __builtin_fmaf(gain, s[r], u[r]);
+    return;
+  }
   const float inv_prior_var = KIND == SDENG_CTRL_LERP ? 1.0f / (a.prior.p1 * a.prior.p1) : 0.0f;
 #pragma unroll
   for (int r = 0; r < 4; ++r)
