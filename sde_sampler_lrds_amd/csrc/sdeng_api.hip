@@ -169,7 +169,7 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   L.ref_dist = o; o += dist_floats(d->ref_dist, dpad);
   L.prior = o; o += dist_floats(d->prior, dpad);
   L.rnd_init = o; o += align64(d->B);
-  L.trash = o; o += align64(SD_THREADS * 4);
+  L.trash = o; o += align64((SD_WAVES_MAX > SD_WAVES ? SD_WAVES_MAX : SD_WAVES) * 64 * 4);
   L.logz = o; o += align64(5 * SD_LOGZ_MAX_BLOCKS);
   L.cmcd = o;
   {  // logistic-regression images (CMCD, or the in-loop score of a Score/LerpCtrl) and the CMCD prior's packed precision

@@ -32,6 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SD_WAVES 8         // waves per workgroup (2 per SIMD, 256-VGPR budget)
 #endif
 #define SD_THREADS (SD_WAVES * 64)
+#define SD_WAVES_MAX 12    // step-loop instantiations that fit the 168-register budget run 3 waves per SIMD (sim_kernel.hpp sd_waves_of)
 
 // Packed drift-net image.  The GEMMs run on the f16 matrix pipe as a two-piece split (see sim_device.hpp,
 // dense_f16x2): every weight is stored as hi = f16(w) and lo = f16((w - hi) * 2^11).  One block = one
@@ -50,8 +51,8 @@ __host__ __device__ inline int sd_pack_floats(int NT) { return sd_lds_weight_flo
 // workgroup-shared copy of a larger mixture's table (RF_GMM_BIG): `share` chunks of 1 KiB per wave, two buffers
 #define SD_SHARE_MAX 4
 __host__ __device__ inline int sd_share_buf_floats(int share) { return share * SD_WAVES * 256; }
-__host__ __device__ inline int sd_lds_total_bytes(int NT, bool with_ref) {
-  return (sd_lds_weight_floats(NT) + (with_ref ? SD_WAVES * SD_REFTAB_FLOATS : 0)) * 4;
+__host__ __device__ inline int sd_lds_total_bytes(int NT, bool with_ref, int waves = SD_WAVES) {
+  return (sd_lds_weight_floats(NT) + (with_ref ? waves * SD_REFTAB_FLOATS : 0)) * 4;
 }
 
 // device-side view of a distribution (tables prepared by k_dist_tables)

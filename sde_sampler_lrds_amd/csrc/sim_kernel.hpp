@@ -74,11 +74,31 @@ SD_INLINE void add_ctrl_score_tile(const SimArgs& a, f32x4& u, const f32x4& sv, 
   }
 }
 
+// Waves per workgroup of an instantiation (one persistent workgroup per CU).  Two per SIMD (256-register budget) by default; THREE per
+// SIMD where the step loop fits the 168-register budget of three waves without scratch: the third wave fills issue slots the other
+// two leave while they wait (PIS phi^4, 131 072 x 512: 18.98 -> 16.4 ms).  The list is the plain sampling kernels (PAR = 0, forward
+// forms) whose register need the build reports at or below 168 (csrc/obj/kernel_resources.txt); kernels with a workgroup-shared
+// table (RF_GMM_BIG / _FULL / _MM) stage it with SD_WAVES waves and stay there.
+template <int NT, int REF, int SC, int FORM, int PAR>
+constexpr int sd_waves_of() {
+#if SD_WAVES != 8
+  return SD_WAVES;  // occupancy experiments (build.py SDENG_WAVES)
+#else
+  if (PAR != 0 || FORM == SDENG_FORM_EUBO) return SD_WAVES;
+  if (REF == RF_NONE && (SC == SC_NONE || SC == SC_PHI4)) return SD_WAVES_MAX;
+  if (REF == RF_GAUSS && SC == SC_NONE && NT <= 5) return SD_WAVES_MAX;
+  if (REF == RF_GMM && SC == SC_NONE && NT <= 6) return SD_WAVES_MAX;
+  return SD_WAVES;
+#endif
+}
+
 // PAR = 1 adds the parity-mode paths (injected noise, trajectory dump); PAR = 0 keeps them out of the step loop.
 template <int NT, int REF, int SC, int FORM, int PAR>
-__global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const SimArgs a) {
+__global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), (sd_waves_of<NT, REF, SC, FORM, PAR>() / 4)) k_simulate(const SimArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int dpad = 16 * NT;
+  constexpr int W = sd_waves_of<NT, REF, SC, FORM, PAR>(), THREADS = 64 * W;
+  static_assert(W == SD_WAVES || !(REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM), "shared-table staging is laid out for SD_WAVES waves");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,10 +106,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
     const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack);
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     const int n4 = sd_lds_weight_floats(NT) / 4;
-    for (int i = tid; i < n4; i += SD_THREADS) dst[i] = src[i];
+    for (int i = tid; i < n4; i += THREADS) dst[i] = src[i];
     if constexpr (SC == SC_LOGREG) {  // the two design-matrix images behind the weights (when they fit: else they stay in L2)
       const int ni = a.lr.in_lds ? sd_lr_floats(NT, a.lr.n_rows) / 4 : 0;
-      for (int i = tid; i < ni; i += SD_THREADS) dst[n4 + i] = reinterpret_cast<const f32x4*>(a.lr.image)[i];
+      for (int i = tid; i < ni; i += THREADS) dst[n4 + i] = reinterpret_cast<const f32x4*>(a.lr.image)[i];
     }
   }
   __syncthreads();
@@ -136,7 +156,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate(const Sim
 
   // CUs first; shared-table mode: the round's wave-0 tile decides, so all 8 waves run the same rounds
   for (int tile = blockIdx.x + gridDim.x * wave; (share ? tile - static_cast<int>(gridDim.x) * wave : tile) < a.ntiles;
-       tile += gridDim.x * SD_WAVES) {
+       tile += gridDim.x * W) {
     const uint32_t row = static_cast<uint32_t>(tile) * 16u + p;
     const bool live = row < static_cast<uint32_t>(a.B);
     const uint32_t pidx = static_cast<uint32_t>(a.particle0 + row);
@@ -586,13 +606,14 @@ static int launch_ctrl_forward(const SimArgs& a, int grid, hipStream_t stream) {
 // host-side launcher, one per instantiation (defined in gen/sim_*.hip)
 template <int NT, int REF, int SC, int FORM, int PAR>
 static int launch_simulate_par(const SimArgs& a, int grid, hipStream_t stream) {
-  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM)) +
+  constexpr int W = sd_waves_of<NT, REF, SC, FORM, PAR>();
+  const size_t lds_bytes = static_cast<size_t>(sd_lds_total_bytes(NT, REF == RF_GAUSS || REF == RF_GMM, W)) +
                            ((SC == SC_LOGREG && a.lr.in_lds) ? sizeof(float) * sd_lr_floats(NT, a.lr.n_rows) : 0) +
                            ((REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM) ? sizeof(float) * 2 * sd_share_buf_floats(a.ref_share) : 0);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_simulate<NT, REF, SC, FORM, PAR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL((k_simulate<NT, REF, SC, FORM, PAR>), dim3(grid), dim3(SD_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL((k_simulate<NT, REF, SC, FORM, PAR>), dim3(grid), dim3(64 * W), lds_bytes, stream, a);
   return static_cast<int>(hipGetLastError());
 }
 template <int NT, int REF, int SC, int FORM>
