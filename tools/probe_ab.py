@@ -1,5 +1,5 @@
 """A/B of library builds on the step loop of one workload: SDENG_LIBS = space-separated library paths ('default' = the in-tree build),
-PROBE_CFG = rds_gmm (default) | pis_phi4 | cmcd_logreg."""
+PROBE_CFG = rds_gmm (default) | pis_phi4 | cmcd_logreg, PROBE_D = another dimension for the same workload."""
 import os
 import subprocess
 import sys
@@ -15,7 +15,8 @@ from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
 dev = torch.device("cuda:0")
 cfg = os.environ.get("PROBE_CFG", "rds_gmm")
 B, N = cfgs.FULL_SIZE[cfg]
-loss, ts, x0, args, kw, info = cfgs.BUILDERS[cfg](dev, B, N)
+extra = {'d': int(os.environ['PROBE_D'])} if os.environ.get('PROBE_D') else {}
+loss, ts, x0, args, kw, info = cfgs.BUILDERS[cfg](dev, B, N, **extra)
 ev = L.HipEvents(); loss.timing_events = ev
 best = 1e9
 for rep in range(12):
