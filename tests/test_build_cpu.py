@@ -42,3 +42,26 @@ def test_isa_hazard_scan_is_clean(unit, tmp_path):
     assert "v_mfma_f32_16x16x32_f16" in text
     assert "v_pk_fma_f32" not in text and "v_pk_mul_f32" not in text and "v_pk_add_f32" not in text, "packed fp32 must stay disabled (DESIGN 4a)"
     assert scan(out, window=20, quiet=True) == []
+
+
+def test_headline_kernels_keep_their_registers():
+    """Registers / scratch / occupancy of the three bench kernels, from the compiler's own remarks of the build
+    (csrc/obj/kernel_resources.txt): a spill or a lost wave in a step loop is a 5-15 % regression that no parity test sees.
+    Every kernel built for three waves per SIMD (sim_kernel.hpp sd_waves_of) must fit that budget without scratch."""
+    from sde_sampler_lrds_amd import build
+
+    build.build(verbose=False)
+    rows = {}
+    for line in open(os.path.join(build.OBJ, "kernel_resources.txt")):
+        if line.startswith("#"):
+            continue
+        unit, name, vgpr, agpr, scratch, occ, lds = line.split()
+        rows[name] = (int(vgpr), int(scratch), int(occ))
+    cfg2 = rows["_Z10k_simulateILi8ELi2ELi0ELi0ELi0EEv7SimArgs"]      # ManyModes d=128, mixture reference, EI
+    cfg3 = rows["_Z10k_simulateILi7ELi0ELi2ELi1ELi0EEv7SimArgs"]      # PhiFour d=100, PIS, EM
+    cfg4 = rows["_Z15k_simulate_cmcdILi4ELi0ELb0ELi0EEv8CmcdArgs"]    # logistic regression d=61, CMCD
+    assert cfg2[1] == 0 and cfg2[2] >= 2, cfg2
+    assert cfg3[1] == 0 and cfg3[2] >= 3 and cfg3[0] <= 168, cfg3
+    assert cfg4[1] == 0 and cfg4[2] >= 2, cfg4
+    three = [(n, r) for n, r in rows.items() if n.startswith("_Z10k_simulateI") and r[2] == 3]
+    assert len(three) >= 40 and all(r[1] == 0 for _, r in three), [x for x in three if x[1][1]][:5]
