@@ -161,10 +161,11 @@ def test_four_mode_reference_forms(gpu, d, B, kind):
 # ---- every kernel family at full occupancy --------------------------------------------------------------------------
 # The golden cases replicated to 32 768+ particles (each replica draws its own Philox noise): reruns and shards must be
 # bit-identical, and blocks of the big run -- chosen so that every wave slot of a workgroup is covered -- must equal a
-# small launch of just that block (one wave per SIMD: the regime the fixtures pin against the reference).
+# small launch of just that block (one wave per SIMD: the regime the fixtures pin against the reference).  Kernels built for three
+# waves per SIMD (sim_kernel.hpp sd_waves_of: the phi^4 and no-reference families, small-d references) have 12 wave slots.
 BIG = [("rds_ei_gmm_d128_k16", 32768), ("rds_ei_gmm_d8_k4", 65536), ("rds_ddpm_gmm_d16_snr", 65536), ("rds_em_gmm_d16", 65536),
        ("rds_ei_vp_default_d16", 65536), ("rds_ei_pbm_default_d16", 65536), ("dds_two_modes_d2", 65536), ("dds_rings_d2", 65536),
-       ("dis_ei_d8", 65536), ("dis_orig_lerp_d8", 65536), ("pis_em_phi4_d100", 32768), ("cmcd_logreg_d61", 32768), ("cmcd_gmm_iso_d16", 65536), ("cmcd_gmm_diag_d40", 32768), ("cmcd_phi4_d100", 32768), ("pis_logreg_d61", 32768), ("dds_logreg_d61", 32768)]
+       ("dis_ei_d8", 65536), ("dis_orig_lerp_d8", 65536), ("pis_em_phi4_d100", 65536), ("cmcd_logreg_d61", 32768), ("cmcd_gmm_iso_d16", 65536), ("cmcd_gmm_diag_d40", 32768), ("cmcd_phi4_d100", 32768), ("pis_logreg_d61", 32768), ("dds_logreg_d61", 32768)]
 
 
 @pytest.mark.gpu
@@ -181,7 +182,7 @@ def test_every_kernel_family_at_full_occupancy(gpu, name, B):
         again = loss.simulate(ts, x0, *args, **kw)
         assert torch.equal(full[0], again[0]) and torch.equal(full[1], again[1]), "rerun differs"
     ntiles, grid = B // 16, min(256, B // 16)
-    for wave in range(8):  # tile = block + grid * (wave + 8 * round): one block per wave slot
+    for wave in range(12):  # tile = block + grid * (wave + W * round), W = 8 or 12 waves per workgroup: one block per wave slot
         tile = 37 + grid * wave
         if tile >= ntiles:
             break
