@@ -342,11 +342,11 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
           for (int j = 0; j < KTM; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              lt[j][r] = (j < kt) ? expf(lt[j][r] - mxv) : 0.0f;
+              lt[j][r] = (j < kt) ? __builtin_amdgcn_exp2f((lt[j][r] - mxv) * 1.4426950408889634f) : 0.0f;  // hardware exp2: arguments <= 0
               den += lt[j][r];
             }
           den = group_sum(den);
-          const float inv = 1.0f / den;
+          const float inv = __builtin_amdgcn_rcpf(den);  // den in [1, 64]
 #pragma unroll
           for (int j = 0; j < KTM; ++j) lt[j] = lt[j] * inv;
         }
