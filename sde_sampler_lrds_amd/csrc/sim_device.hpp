@@ -15,6 +15,10 @@ SD_INLINE float group_sum(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+// exp of a non-positive argument / reciprocal of a sum of such terms, for softmax weights: the hardware exp2 and reciprocal
+// (1 ulp each).  libm's expf spends ~15 instructions on overflow / denormal handling that cannot occur here, the IEEE division ~10.
+SD_INLINE float exp_nonpos(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
+SD_INLINE float rcp_fast(float v) { return __builtin_amdgcn_rcpf(v); }
 
 // torch.clip semantics: NaN stays NaN (fminf/fmaxf or v_med3 would swallow it).
 SD_INLINE float clampf(float v, float m) {
@@ -467,8 +471,8 @@ SD_INLINE void gmm_score_accum(const f32x4 (&x)[NT], const float* __restrict__ t
     const float v = ((-0.5f * part) - c1) - consts[k * cstride + 0];
     const float lp = consts[k * cstride + 1] + v;
     const float m_new = fmaxf(m_run, lp);
-    const float so = expf(m_run - m_new);
-    const float pk = expf(lp - m_new);
+    const float so = exp_nonpos(m_run - m_new);
+    const float pk = exp_nonpos(lp - m_new);
     l_run = l_run * so + pk;
     if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
 #pragma unroll
@@ -495,7 +499,7 @@ SD_INLINE void gmm_score_begin(f32x4 (&acc)[NT], float& m_run, float& l_run) {
 }
 template <int NT>
 SD_INLINE void gmm_score_end(f32x4 (&acc)[NT], float l_run) {
-  const float inv = 1.0f / l_run;
+  const float inv = rcp_fast(l_run);
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = acc[t] * inv;
 }
@@ -531,10 +535,10 @@ SD_INLINE void gmm_resp(const f32x4 (&x)[NT], const float* __restrict__ tab, con
   float den = 0.0f;
 #pragma unroll
   for (int k = 0; k < SD_KREG; ++k) {
-    p[k] = (k < K) ? expf(lp[k] - mx) : 0.0f;
+    p[k] = (k < K) ? exp_nonpos(lp[k] - mx) : 0.0f;
     den += p[k];
   }
-  const float inv = 1.0f / den;
+  const float inv = rcp_fast(den);
 #pragma unroll
   for (int k = 0; k < SD_KREG; ++k) p[k] *= inv;
 }
@@ -609,15 +613,13 @@ SD_INLINE void gmm_resp_centred(const f32x4 (&x)[NT], const float* __restrict__ 
     lp[k] = consts[2 * k + 1] + group_sum(lp[k]);
     mx = fmaxf(mx, lp[k]);
   }
-  // softmax with the hardware exp2 / reciprocal (1 ulp each; the arguments are <= 0 and the sum is in [1, 4]): libm's expf and the
-  // IEEE division cost ~15 and ~10 instructions apiece for range handling that cannot occur here
   float den = 0.0f;
 #pragma unroll
   for (int k = 0; k < SD_KREG; ++k) {
-    p[k] = __builtin_amdgcn_exp2f((lp[k] - mx) * 1.4426950408889634f);
+    p[k] = exp_nonpos(lp[k] - mx);
     den += p[k];
   }
-  const float inv = __builtin_amdgcn_rcpf(den);
+  const float inv = rcp_fast(den);
 #pragma unroll
   for (int k = 0; k < SD_KREG; ++k) p[k] *= inv;
 }

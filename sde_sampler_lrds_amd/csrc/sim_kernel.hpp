@@ -342,11 +342,11 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
           for (int j = 0; j < KTM; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              lt[j][r] = (j < kt) ? __builtin_amdgcn_exp2f((lt[j][r] - mxv) * 1.4426950408889634f) : 0.0f;  // hardware exp2: arguments <= 0
+              lt[j][r] = (j < kt) ? exp_nonpos(lt[j][r] - mxv) : 0.0f;
               den += lt[j][r];
             }
           den = group_sum(den);
-          const float inv = __builtin_amdgcn_rcpf(den);  // den in [1, 64]
+          const float inv = rcp_fast(den);
 #pragma unroll
           for (int j = 0; j < KTM; ++j) lt[j] = lt[j] * inv;
         }
@@ -423,8 +423,8 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
           quad = group_sum(quad);
           const float lp = rcs[c * 2 + 1] + (((-0.5f * quad) - a.ref_c1) - rcs[c * 2 + 0]);
           const float m_new = fmaxf(m_run, lp);
-          const float so = expf(m_run - m_new);
-          const float pk = expf(lp - m_new);
+          const float so = exp_nonpos(m_run - m_new);
+          const float pk = exp_nonpos(lp - m_new);
           l_run = l_run * so + pk;
           m_run = m_new;
 #pragma unroll
