@@ -32,6 +32,8 @@ if not PACKED:
     FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 if os.environ.get("SDENG_DEFS"):  # experiment knob: extra -D flags (ablation builds)
     FLAGS += ["-D" + d for d in os.environ["SDENG_DEFS"].split()]
+if os.environ.get("SDENG_CXXFLAGS"):  # experiment knob: extra compiler flags (e.g. "-mllvm -amdgpu-sched-strategy=iterative-ilp")
+    FLAGS += os.environ["SDENG_CXXFLAGS"].split()
 if os.environ.get("SDENG_WAVES"):  # experiment knob: waves per workgroup (8 = 2 per SIMD, 4 = 1 per SIMD)
     FLAGS.append("-DSD_WAVES=" + os.environ["SDENG_WAVES"])
 

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the cfg-2 step-loop kernel on ONE box: the round-1 library (tree extracted to .ab_r01/, built there) against the current one,
+# A/B of the cfg-2 step-loop kernel on ONE box: the round-1 library (mkdir .ab_r01 && git archive 80d3ce0 | tar -x -C .ab_r01, then
+# python -m sde_sampler_lrds_amd.build inside it) against the current one,
 # alternating, kernel durations from rocprofv3 --kernel-trace.   usage: tools/ab_rounds.sh  (on the GPU box)
 set -u
 R=$GRAFT_REPO_ROOT
