@@ -161,9 +161,9 @@ class BaseOCLoss:
         """Log-variance training value (losses/oc.py ``__call__`` of every loss, method in ('lv', 'lv_traj')).  The
         trajectories are driven by the DETACHED control (generative_and_sde_ctrl, :83-103), so the states carry no graph
         and the step loop is exactly the eval path: it runs as one HIP launch (``simulate(x, z)`` with the trajectory and
-        the noise kept), and the log-weights are then rebuilt with autograd by ONE batched pass of the control over all
-        N*B (time, state) pairs:
-            rnd = rnd0 + sum_k c_k <u_k, u_k.detach() - u_k/2> + c'_k <u_k, z_k> + terminal(x_N)
+        the noise kept) and its log-weights ARE the loss's
+            rnd = rnd0 + sum_k c_k <u_k, u_k.detach() - u_k/2> + c'_k <u_k, z_k> + terminal(x_N);
+        their gradient comes from ONE batched pass of the control over all N*B (time, state) pairs
         (:269-271, :284 EM; :490-491, :499 EI / DDPM-like; :957-958, :965 DIS; :1361-1383 DDS).  KL training differentiates
         through the trajectory and is not on this path."""
         if self.method not in ("lv", "lv_traj"):
@@ -181,18 +181,23 @@ class BaseOCLoss:
         seed_c = (int(self.seed) + 0x9E3779B97F4A7C15 * self.train_calls) & 0xFFFFFFFFFFFFFFFF
         self.train_calls += 1
         z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)
+        # VALUE: the step loop already integrates exactly this rnd (the detached control is the control), terminal terms included.
         with torch.no_grad():
-            x_n, _, xs = simulate(x, z)
-            const = terminal(x_n)
+            x_n, rnd_sim, xs = simulate(x, z)
+            rnd_val = rnd_sim.reshape(B, 1)
             if rnd0 is not None:
-                const = const + self._logp(rnd0, x)
+                rnd_val = rnd_val + self._logp(rnd0, x)
+        # GRADIENT: d rnd_b / d u_kb = c_k (u.detach() - u) + c'_k z_kb = c'_k z_kb -- the running-cost term has zero gradient at
+        # u.detach() = u (in fp32 too: (u - u/2) - u/2 = 0 exactly, which is what the reference's autograd produces).  So the only
+        # part of rnd that needs a graph is the stochastic integral s_b = sum_k c'_k <u_kb, z_kb>, from one batched pass of the
+        # control; it enters with value zero (s - s.detach()), and compute_loss / backward() do the rest as upstream.
         coef = self._coef(ts, x.device, **(coef_kw or {}))
-        c_run = (2.0 * coef[:, 4]) if lin else coef[:, 4]  # omega | beta^2 sigma^2 (LIN forms)  or dt (EM)
         u = ctrl_batched(self.generative_ctrl, coef[:, 0], xs[:-1])  # coef[:, 0]: the net's time of step k
-        rnd = ((u * (u.detach() - 0.5 * u)).sum(dim=-1).view(N, B) * c_run.view(N, 1)).sum(dim=0)
         if ito:
-            rnd = rnd + ((u * z.view(N * B, d)).sum(dim=-1).view(N, B) * coef[:, 5].view(N, 1)).sum(dim=0)
-        return self.compute_loss(rnd.view(B, 1) + const, samples=x_n)
+            s = ((u * z.view(N * B, d)).sum(dim=-1).view(N, B) * coef[:, 5].view(N, 1)).sum(dim=0)
+        else:
+            s = (u * 0.0).sum(dim=-1).view(N, B).sum(dim=0)
+        return self.compute_loss(rnd_val + (s - s.detach()).view(B, 1), samples=x_n)
 
     # ---- engine plumbing ---------------------------------------------------------------------
     @staticmethod
