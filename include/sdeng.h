@@ -92,7 +92,7 @@ extern "C" {
                                       a quarter of the features each) instead of one -- ~2x lower latency when the batch cannot fill the
                                       chip.  Same noise counters; sums are formed in another order, so results equal the default path's
                                       to fp32 round-off, not bit for bit.  Honoured for ClippedCtrl, LIN / EM forms, no / Gaussian /
-                                      small-mixture reference, d > 64, no xs_out / noise_in; ignored otherwise. */
+                                      small-mixture reference, d > 64, no noise_in (xs_out is written); ignored otherwise. */
 
 /* ---- distributions (the distr package): log-density and score by hand-coded formulas ------------ */
 #define SDENG_DIST_NONE 0

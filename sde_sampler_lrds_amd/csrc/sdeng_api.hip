@@ -121,7 +121,7 @@ static bool use_mm(const sdeng_desc* d, int DT);
 // SDENG_FLAG_SPLIT_TILES: is the low-latency kernel built for this call?  (The reference kind is checked where it is known.)
 static bool split_eligible(const sdeng_desc* d, int DT) {
   return (d->flags & SDENG_FLAG_SPLIT_TILES) && d->B <= 8192 && DT >= 5 && d->net.ctrl_kind == SDENG_CTRL_CLIPPED &&
-         (d->form == SDENG_FORM_LIN || d->form == SDENG_FORM_EM) && !d->xs_out && !d->noise_in &&
+         (d->form == SDENG_FORM_LIN || d->form == SDENG_FORM_EM) && !d->noise_in &&
          (d->ref.kind == SDENG_REF_NONE || d->ref.kind == SDENG_REF_GAUSS_DIAG || (d->ref.kind == SDENG_REF_GMM_DIAG && d->ref.k <= 4));
 }
 static int check_x0_dist(const sdeng_desc* d);

@@ -99,6 +99,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
     f32x4 x[2] = {zero, zero};
     if (has0) x[0] = load_quad(a.x_in, row, a.d, live, t0, g);
     if (has1) x[1] = load_quad(a.x_in, row, a.d, live, t1, g);
+    if (a.xs_out) {
+      if (has0) store_quad(a.xs_out, trash, row, a.d, live, t0, g, x[0]);
+      if (has1) store_quad(a.xs_out, trash, row, a.d, live, t1, g, x[1]);
+    }
     float rnd = 0.0f;  // this wave's share of the log-weight (its features' cost terms; wave 0 also carries rnd0 and the per-step constants)
     if (w == 0 && a.rnd_init) rnd = live ? a.rnd_init[row] : 0.0f;
     if (a.N > 0) fetch_table(0);
@@ -287,6 +291,11 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
       if constexpr (REF != RF_NONE) {  // every read of this step's table is done: fetch the next one
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < a.N) fetch_table(k + 1);
+      }
+      if (a.xs_out) {  // trajectory (return_traj, log-variance training): each wave stores its own feature tiles of state k + 1
+        float* xs = a.xs_out + static_cast<size_t>(k + 1) * a.B * a.d;
+        if (has0) store_quad(xs, trash, row, a.d, live, t0, g, x[0]);
+        if (has1) store_quad(xs, trash, row, a.d, live, t1, g, x[1]);
       }
       // running cost and stochastic integral of the own features (the sums over features are linear: the four shares add up)
       su2 = group_sum(su2);

@@ -59,6 +59,18 @@ def ctrl_batched(ctrl, t_unique: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return out + (ctrl.sde.diff(t_rows, flat) * score if name == "LerpCtrl" else score)
 
 
+class _IntegralPass(torch.nn.Module):
+    """s_b = sum_k <u(t_k, x_kb), zc_kb>: the one part of the log-variance loss that carries a graph (BaseOCLoss._lv_loss)."""
+
+    def __init__(self, ctrl):
+        super().__init__()
+        self.ctrl = ctrl
+
+    def forward(self, t_unique, xs, zc):
+        u = ctrl_batched(self.ctrl, t_unique, xs)
+        return (u * zc).sum(dim=-1).view(xs.shape[0], xs.shape[1]).sum(dim=0)
+
+
 class BaseOCLoss:
     """Mirror of losses/oc.py:14-200."""
 
@@ -92,6 +104,8 @@ class BaseOCLoss:
         self._coef_cache = {}
         self._cpu_sde = None
         self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
+        self.graph_training = False  # True: the batched control pass of log-variance training (forward + backward) is replayed as a hipGraph (_IntegralPass)
+        self._graphed = {}
         self.split_tiles = False  # True: small batches (<= 16 384) ask for the low-latency kernels (SDENG_FLAG_SPLIT_TILES; fp32-round-off, not bit, equal)
         self.dist = None  # torch.distributed of a sharded run: eval() then returns global estimators and globally normalised weights
 
@@ -182,8 +196,15 @@ class BaseOCLoss:
         self.train_calls += 1
         z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)
         # VALUE: the step loop already integrates exactly this rnd (the detached control is the control), terminal terms included.
+        # (the kernel draws the normals of stream seed_c itself -- bit for bit the z above -- so nothing is injected and small
+        # batches may take the low-latency split-tile kernel, which writes the trajectory but does not replay noise)
+        seed_eval, self.seed = self.seed, seed_c
+        try:
+            with torch.no_grad():
+                x_n, rnd_sim, xs = simulate(x, None)
+        finally:
+            self.seed = seed_eval
         with torch.no_grad():
-            x_n, rnd_sim, xs = simulate(x, z)
             rnd_val = rnd_sim.reshape(B, 1)
             if rnd0 is not None:
                 rnd_val = rnd_val + self._logp(rnd0, x)
@@ -191,13 +212,30 @@ class BaseOCLoss:
         # u.detach() = u (in fp32 too: (u - u/2) - u/2 = 0 exactly, which is what the reference's autograd produces).  So the only
         # part of rnd that needs a graph is the stochastic integral s_b = sum_k c'_k <u_kb, z_kb>, from one batched pass of the
         # control; it enters with value zero (s - s.detach()), and compute_loss / backward() do the rest as upstream.
-        coef = self._coef(ts, x.device, **(coef_kw or {}))
-        u = ctrl_batched(self.generative_ctrl, coef[:, 0], xs[:-1])  # coef[:, 0]: the net's time of step k
-        if ito:
-            s = ((u * z.view(N * B, d)).sum(dim=-1).view(N, B) * coef[:, 5].view(N, 1)).sum(dim=0)
-        else:
-            s = (u * 0.0).sum(dim=-1).view(N, B).sum(dim=0)
+        coef = self._coef(ts, x.device, **(coef_kw or {}))  # coef[:, 0]: the net's time of step k, coef[:, 5]: c'_k
+        zc = (z.view(N, B, d) * (coef[:, 5] if ito else torch.zeros_like(coef[:, 5])).view(N, 1, 1)).view(N * B, d)
+        s = self._integral_pass(coef[:, 0].contiguous(), xs[:-1], zc)
         return self.compute_loss(rnd_val + (s - s.detach()).view(B, 1), samples=x_n)
+
+    def _integral_pass(self, t_unique, xs, zc):
+        """The batched control pass, eager or -- ``graph_training`` -- as a captured graph per (shape, control): at the reference's
+        training sizes the ~150 small kernels of its forward + backward are host-launch bound (tools/probe_training.py).  Only for the
+        pure-torch controls (ClippedCtrl over a FourierMLP); anything else, or a capture that fails, runs eagerly."""
+        ctrl = self.generative_ctrl
+        key = (id(ctrl), tuple(xs.shape), str(xs.device))
+        fn = self._graphed.get(key)
+        if fn is None:
+            fn = _IntegralPass(ctrl)
+            if self.graph_training and type(ctrl).__name__ == "ClippedCtrl" and type(getattr(ctrl, "base_model", None)).__name__ == "FourierMLP":
+                try:
+                    sample = (t_unique.detach().clone(), xs.detach().clone(), zc.detach().clone())
+                    fn = torch.cuda.make_graphed_callables(fn, sample)
+                except Exception as e:  # noqa: BLE001 -- capture is an optimisation: fall back to the eager pass, say so once
+                    import warnings
+                    warnings.warn(f"log-variance training: graph capture of the batched control pass failed ({type(e).__name__}: {e}); running it eagerly")
+                    fn = _IntegralPass(ctrl)
+            self._graphed[key] = fn
+        return fn(t_unique, xs.contiguous(), zc)
 
     # ---- engine plumbing ---------------------------------------------------------------------
     @staticmethod

@@ -112,6 +112,7 @@ class TrainableDiff:
         loss = cls(self.generative_ctrl, self.generative_ctrl_ema, sde=self.sde,
                    filter_samples=getattr(self.target, "filter", None), **c, **extra)
         loss.seed = self.seed
+        loss.graph_training = bool(self.cfg.get("graph_training", False))  # log-variance training: batched control pass as a hipGraph (works; measured no gain: the step is bound by its read-backs, tools/probe_train_host.py)
         loss.split_tiles = bool(self.cfg.get("split_tiles", True))  # evaluation batches of a few thousand particles: low-latency kernels
         return loss
 
