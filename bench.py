@@ -219,13 +219,14 @@ def path_of(cfg, info):
         small = K <= 4 and K * 2 * 16 * ((info["d"] + 15) // 16) <= 1024
         return (f"k_simulate<NT={(info['d'] + 15) // 16},REF={'GMM' if small else 'GMM_BIG'},SC=NONE,FORM=LIN>: "
                 + ("K <= 4: responsibilities in registers, per-wave LDS table by LDS-DMA; all components share one variance vector "
-                   "(variances_init = 0.5, the reference's default initialisation) -> shared-variance score form "
-                   "(a fitted reference with distinct variances runs the general form, ~2-3 % slower)" if small
+                   "(variances_init = 0.5, the reference's default initialisation) -> centred shared-variance form, one fma per element and "
+                   "component (a fitted reference with distinct variances runs the general form: 3 + 2 per element and component); "
+                   "8 waves per workgroup = 2 per SIMD" if small
                    else "K > 4: workgroup-shared double-buffered LDS table, online softmax"))
     if cfg == "pis_phi4":
-        return f"k_simulate<NT={(info['d'] + 15) // 16},REF=NONE,SC=PHI4,FORM=EM>: ScoreCtrl with the phi^4 lattice score in registers (neighbour exchange by cross-lane moves)"
+        return f"k_simulate<NT={(info['d'] + 15) // 16},REF=NONE,SC=PHI4,FORM=EM>: ScoreCtrl with the phi^4 lattice score in registers (neighbour exchange by cross-lane moves); 12 waves per workgroup = 3 per SIMD (the step loop fits 168 registers)"
     return ("k_simulate_cmcd<NT=4,LOGREG>: one drift-net + one annealed-score evaluation per step (the reference: 2 + 4), design matrix in "
-            "LDS as split-f16 MFMA images, full-covariance prior precision through L2")
+            "LDS as split-f16 MFMA images, full-covariance prior precision through L2; 8 waves per workgroup = 2 per SIMD")
 
 
 def config_entry(m, cpu_budget_s, chunk, with_cpu):
