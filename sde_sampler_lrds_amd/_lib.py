@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m sde_sampler_lrds_amd.build` "
                           "(there is no CPU fallback for the simulate path)")
+    import torch  # noqa: F401 -- before the library: libsdeng.so then binds to the HIP runtime torch has loaded (its own copy), instead
+    #                          of bringing /opt/rocm's into the process first; with two runtimes the library's launches find no device
     L = C.CDLL(LIB_PATH)
     L.sdeng_abi_version.restype = C.c_int
     L.sdeng_last_error.restype = C.c_char_p
