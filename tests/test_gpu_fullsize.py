@@ -158,6 +158,50 @@ def test_four_mode_reference_forms(gpu, d, B, kind):
     assert bool(torch.isfinite(rnd).all())
 
 
+# ---- the 12-wave (three per SIMD) instantiations without a fixture of their own at full occupancy ------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,d", [("none", 96), ("none", 128), ("gaussian", 64), ("gmm", 48)])
+def test_three_wave_kernels_at_full_occupancy(gpu, kind, d):
+    """No reference + ClippedCtrl (every tile count), Gaussian / mixture reference up to four tiles: built for 12 waves per workgroup
+    (sim_kernel.hpp sd_waves_of).  40 000 particles = every wave slot busy, ragged last round: reruns and shards bit-equal, and blocks
+    of the big run -- one per wave slot -- equal a small launch of just that block."""
+    from sde_sampler_lrds_amd.distr.gauss import ManyModes
+    from sde_sampler_lrds_amd.eq.sdes import VP, ScaledBM
+    from sde_sampler_lrds_amd.losses import oc
+    from sde_sampler_lrds_amd.models.reparam import ClippedCtrl
+    from sde_sampler_lrds_amd.reference import MarginalReference
+    torch.manual_seed(d)
+    B, N = 40000 + 7, 10
+    target = ManyModes(n_modes=3, dim=d, var=0.5, seed_loc=1, n_reference_samples=10)
+    ctrl = ClippedCtrl(base_model=cfgs._net(d), clip_model=1e4)
+    if kind == "none":
+        sde, ref = ScaledBM(diff_coeff=0.4, terminal_t=2.0), None
+    else:
+        sde = VP(0.1, 10.0, 1.0, terminal_t=1.0)
+        ref = (MarginalReference(sde, "gaussian", x_init=0.3 * torch.randn(d), var_init=0.5 + torch.rand(d)) if kind == "gaussian" else
+               MarginalReference(sde, "gmm", means_init=target.loc.clone(), variances_init=0.3 + torch.rand(3, d), weights_init=torch.tensor([1.0, 2.0, 3.0])))
+    for m in (sde, target, ctrl, ref):
+        if m is not None:
+            m.to(gpu)
+    loss = (oc.EMReferenceSDELoss if kind == "none" else oc.EIReferenceSDELoss)(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref)
+    loss.seed = 31
+    ts = torch.linspace(0.0, float(sde.terminal_t), N + 1, device=gpu)
+    x0 = torch.randn(B, d, device=gpu)
+    refd = ref.reference_distr.to(gpu).log_prob if ref is not None else (lambda x: torch.zeros(x.shape[0], device=x.device))
+    args = (target.unnorm_log_prob, refd)
+    full = _run_full_and_shards(loss, ts, x0, args, {})
+    ntiles, grid = (B + 15) // 16, 256
+    for wave in range(12):
+        tile = 11 + grid * wave
+        if tile >= ntiles:
+            break
+        lo = 16 * tile - 8
+        loss.particle0 = lo
+        part = loss.simulate(ts, x0[lo:lo + 48].contiguous(), *args)
+        assert torch.equal(part[0], full[0][lo:lo + 48]) and torch.equal(part[1], full[1][lo:lo + 48]), f"wave slot {wave}"
+    loss.particle0 = 0
+
+
 # ---- every kernel family at full occupancy --------------------------------------------------------------------------
 # The golden cases replicated to 32 768+ particles (each replica draws its own Philox noise): reruns and shards must be
 # bit-identical, and blocks of the big run -- chosen so that every wave slot of a workgroup is covered -- must equal a
