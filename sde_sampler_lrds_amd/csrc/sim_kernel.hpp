@@ -191,6 +191,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       const float* cf = a.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5], c6 = cf[6];
       const float score_gain = cf[7], lerp_w = cf[8];
+      const float e1 = __builtin_fmaf(c4, c1, 1.0f), e2 = c4 * c2, e3 = c4 * c3, e4 = c2 * c5;  // EM update, see the tail
       // `d` re-read through an opaque move every step: keeps the pad masks (f < d) from being hoisted out of
       // the step loop, where they would occupy SGPR pairs and spill
       int d_dyn = a.d;
@@ -498,11 +499,12 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
               x[t][r] = __builtin_fmaf(c3, z[r], __builtin_fmaf(c2, sc, c1 * xv));
               suz = __builtin_fmaf(uv, z[r], suz);
             } else {  // losses/oc.py:277-284
-              const float db = z[r] * c5;
-              float f = c1 * xv;
-              if constexpr (REF != RF_NONE) f = __builtin_fmaf(c3, rq[r], f);
-              x[t][r] = __builtin_fmaf(c2, db, __builtin_fmaf(__builtin_fmaf(c2, uv, f), c4, xv));
-              suz = __builtin_fmaf(uv, db, suz);
+              // x + (c1 x + c3 ref + c2 u) dt + c2 sqrt(dt) z with the per-step products formed once (e1 = 1 + c1 dt, e2 = c2 dt,
+              // e3 = c3 dt, e4 = c2 sqrt(dt)): three fused instructions per element; <u, db> = sqrt(dt) <u, z> is scaled after the sum
+              float acc = e1 * xv;
+              if constexpr (REF != RF_NONE) acc = __builtin_fmaf(e3, rq[r], acc);
+              x[t][r] = __builtin_fmaf(e4, z[r], __builtin_fmaf(e2, uv, acc));
+              suz = __builtin_fmaf(uv, z[r], suz);
             }
           }
         }
@@ -528,7 +530,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
         rnd += c6;
         if (a.flags & SDENG_FLAG_ITO) {
           suz = group_sum(suz);
-          rnd += lin ? c5 * suz : suz;
+          rnd += c5 * suz;  // LIN: sqrt(omega) <u, z> (:499); EM: <u, db>, db = sqrt(dt) z (:284)
         }
       }
       if constexpr (PAR) {

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
     for (int k = 0; k < a.N; ++k) {
       const float* cf = a.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5], c6 = cf[6];
+      const float e1 = __builtin_fmaf(c4, c1, 1.0f), e2 = c4 * c2, e3 = c4 * c3, e4 = c2 * c5;
       const float* rcs = a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2;
       const f32x4 te = te_next;
       float rc0[SD_KREG] = {0.0f, 0.0f, 0.0f, 0.0f}, rc1[SD_KREG] = {0.0f, 0.0f, 0.0f, 0.0f};  // mixture constants, read ahead of the barriers
@@ -278,11 +279,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
                 x[j][r] = __builtin_fmaf(c3, z[r], __builtin_fmaf(c2, sc, c1 * xv));
                 suz = __builtin_fmaf(uv, z[r], suz);
               } else {              // losses/oc.py:277-284
-                const float db = z[r] * c5;
-                float f = c1 * xv;
-                if constexpr (REF != RF_NONE) f = __builtin_fmaf(c3, rq[r], f);
-                x[j][r] = __builtin_fmaf(c2, db, __builtin_fmaf(__builtin_fmaf(c2, uv, f), c4, xv));
-                suz = __builtin_fmaf(uv, db, suz);
+                float acc = e1 * xv;  // (sim_kernel.hpp, EM update)
+                if constexpr (REF != RF_NONE) acc = __builtin_fmaf(e3, rq[r], acc);
+                x[j][r] = __builtin_fmaf(e4, z[r], __builtin_fmaf(e2, uv, acc));
+                suz = __builtin_fmaf(uv, z[r], suz);
               }
             }
           }
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
       if (w == 0) rnd += c6;
       if (a.flags & SDENG_FLAG_ITO) {
         suz = group_sum(suz);
-        rnd += lin ? c5 * suz : suz;
+        rnd += c5 * suz;
       }
     }
 
