@@ -206,6 +206,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     for (int k = 0; k < s.N; ++k) {
       const float* cf = s.coef + static_cast<size_t>(k) * SDENG_NCOEF;
       const float dt = cf[2], sqdt = cf[3];
+      const float g_dt = gg * dt, g_sqdt = gg * sqdt;
       // the Philox key re-read through an opaque move every step: left alone, the compiler hoists the ten round keys (20 SGPRs) out of
       // the step loop, runs out of scalar registers and spills them to VGPR lanes -- one v_readlane + wait states per key and use
       uint32_t key_lo = s.seed_lo, key_hi = s.seed_hi;
@@ -222,12 +223,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
 #pragma unroll
           for (int r = 0; r < 4; ++r) z[r] = feat_live<NT>(t, r, 4 * g, s.d) ? z[r] : 0.0f;
         }
+        db[t] = z;  // the normals; db = sqrt(dt) z is applied through the per-step products g sqrt(dt) and (below) sqrt(dt) <c, z>
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dbv = sqdt * z[r];
-          db[t][r] = dbv;
-          x[t][r] = __builtin_fmaf(gg, dbv, __builtin_fmaf(w_s[t][r] * gg, dt, x[t][r]));  // fused (sim_kernel.hpp, update)
-        }
+        for (int r = 0; r < 4; ++r) x[t][r] = __builtin_fmaf(g_sqdt, z[r], __builtin_fmaf(w_s[t][r], g_dt, x[t][r]));  // fused (sim_kernel.hpp, update)
       }
       // cost = (b_s + b_t)/g + u_s - u_t ;  rnd += 0.5 |cost|^2 dt + <cost, db>   (losses/oc.py:737-742; subtracted at :815-818)
       float c2 = 0.0f, cdb = 0.0f;
@@ -254,7 +252,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
       c2 = group_sum(c2);
       cdb = group_sum(cdb);
       rnd += sgn * ((0.5f * c2) * dt);
-      rnd += sgn * cdb;
+      rnd += sgn * (cdb * sqdt);
       if constexpr (PAR != 0) {
         if (s.xs_out) store_rows<NT>(s.xs_out + static_cast<size_t>(k + 1) * s.B * s.d, trash, row, s.d, live, g, x);
       }
