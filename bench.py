@@ -136,7 +136,13 @@ def roofline(cfg, info, B, N, k_ms, extra_flops=0):
                                      "operand splits, reference score) issue in the same slots.  `frac` above can pass 1 (cfg 4, whose likelihood "
                                      "adds two GEMMs per step): three f16 products cost 3/16 of one fp32 MFMA, so the fp32-equivalent rate "
                                      "is an accounting figure, not a ceiling of this pipe."}
-        r["issue"] = {"bound": "vector + matrix instruction issue per SIMD (they do not overlap on gfx950)",
+        wps = 3 if cfg == "pis_phi4" else 2  # waves per SIMD of the instantiation (sim_kernel.hpp sd_waves_of)
+        port = None
+        if "SQ_ACTIVE_INST_VALU" in c and c.get("SQ_WAVE_CYCLES"):
+            port = {"waves_per_simd": wps, "valu_port_busy": wps * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                    "reading": "share of a SIMD's cycles in which its vector port is issuing (vector + matrix instructions): "
+                               "waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, per-wave counters of the same PMC passes"}
+        r["issue"] = {"bound": "vector + matrix instruction issue per SIMD (they do not overlap on gfx950)", "port": port,
                       "instr_per_tile_step": {k: v / tile_steps for k, v in counts.items()},
                       "vector_instr_per_tile_step": c["SQ_INSTS_VALU"] / tile_steps, "issue_cost_ns": ISSUE_NS,
                       "model_ms": model_ms, "kernel_ms": k_ms, "frac": model_ms / k_ms,
