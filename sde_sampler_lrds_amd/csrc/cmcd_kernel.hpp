@@ -38,6 +38,10 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   asm volatile("" ::: "memory");
   f16x8 xh[KB], xl[KB];
   split_tiles<NT>(x, xh, xl);
+  // From here to the end of the hidden layers the wave is in chains of dependent matrix instructions (score products, prior precision,
+  // drift net): it wins issue arbitration against the other wave of its SIMD meanwhile (sim_kernel.hpp, same reason).  Measured on
+  // cfg 4, same box: 6.81 ms without, 6.61 around the hidden layers only, 6.47 from here.
+  __builtin_amdgcn_s_setprio(1);
 
   f32x4 ts[NT];
   if constexpr (TGT == CT_PHI4) {
@@ -118,6 +122,7 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   // ---- control ----
   f32x4 hid[SD_HT];
   mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane);
+  __builtin_amdgcn_s_setprio(0);  // end of the matrix phase (raised at the top of this function)
   const HidSplit hs = split_hidden(hid);
   const float st = s.stheta ? s.stheta[ki] : 1.0f;
 #pragma unroll

@@ -221,7 +221,13 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
 
       // ---- drift net up to the last hidden activation (split-f16 MFMA chain) ----
       f32x4 hid[SD_HT];
+      // The three hidden layers are one long chain of dependent matrix instructions: while a wave is in it, it wins the SIMD's issue
+      // arbitration against the other wave(s), whose vector stream (noise, mixture score, tail) would otherwise be interleaved
+      // between its MFMAs and stretch the chain.  Measured, same box: cfg 2 5.28 -> 4.70 ms, cfg 3 15.74 -> 14.84 ms; priority 1, 2
+      // and 3 are equal; raising it around the output-layer MFMAs of the tail as well is slightly worse (4.73 / 15.09).
+      __builtin_amdgcn_s_setprio(1);
       mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
+      __builtin_amdgcn_s_setprio(0);
       const HidSplit hs = split_hidden(hid);
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
