@@ -6,6 +6,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sde_sampler_lrds_amd import _lib as L  # noqa: E402
+if os.environ.get("SDENG_LIB"):  # A/B against another build of the library
+    L.LIB_PATH = os.path.abspath(os.environ["SDENG_LIB"])
 from sde_sampler_lrds_amd.distr.gauss import ManyModes  # noqa: E402
 from sde_sampler_lrds_amd.eq.sdes import VP  # noqa: E402
 from sde_sampler_lrds_amd.experiments.baseline_configs import _net  # noqa: E402

@@ -2,6 +2,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sde_sampler_lrds_amd import _lib as L
+if os.environ.get("SDENG_LIB"):  # A/B against another build of the library
+    L.LIB_PATH = os.path.abspath(os.environ["SDENG_LIB"])
 from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
 dev = torch.device("cuda:0")
 for B, N in ((6000, 256), (2048, 256), (512, 100)):
