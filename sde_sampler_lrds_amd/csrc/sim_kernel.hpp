@@ -76,19 +76,19 @@ SD_INLINE void add_ctrl_score_tile(const SimArgs& a, f32x4& u, const f32x4& sv, 
 
 // Waves per workgroup of an instantiation (one persistent workgroup per CU).  Two per SIMD (256-register budget) by default; THREE per
 // SIMD where the step loop fits the 168-register budget of three waves without scratch: the third wave fills issue slots the other
-// two leave while they wait (PIS phi^4, 131 072 x 512: d = 100 18.9 -> 16.1 ms, d = 128 20.3 -> 17.5, d = 40 12.4 -> 11.1).  The list is the plain sampling kernels (PAR = 0, forward
+// two leave while they wait (PIS phi^4, 131 072 x 512, d = 100: 18.9 -> 16.1 ms before the matrix-phase priority below existed, 16.1 -> 15.6
+// with it).  The list is the plain sampling kernels (PAR = 0, forward
 // forms) whose register need the build reports at or below 168 (csrc/obj/kernel_resources.txt); kernels with a workgroup-shared
 // table (RF_GMM_BIG / _FULL / _MM) stage it with SD_WAVES waves and stay there.
 template <int NT, int REF, int SC, int FORM, int PAR>
 constexpr int sd_waves_of() {
-#if SD_WAVES != 8
-  return SD_WAVES;  // occupancy experiments (build.py SDENG_WAVES)
+#if SD_WAVES != 8 || defined(SD_NO_W12)
+  return SD_WAVES;  // occupancy experiments (build.py SDENG_WAVES; SD_NO_W12: two waves per SIMD everywhere)
 #else
   if (PAR != 0 || FORM == SDENG_FORM_EUBO) return SD_WAVES;
   if (REF == RF_NONE && (SC == SC_NONE || SC == SC_PHI4)) return SD_WAVES_MAX;
-  // per-wave LDS tables: measured on cfg 2's model, 65 536 x 256: d = 64 3.48 vs 3.58 ms, but d = 96 4.63 vs 4.41 (slower) -- the
-  // table reads of twelve waves crowd the LDS port; so only up to four feature tiles
-  if ((REF == RF_GAUSS || REF == RF_GMM) && SC == SC_NONE && NT <= 4) return SD_WAVES_MAX;
+  // (kernels with per-wave LDS reference tables stay at two waves per SIMD: with the matrix-phase priority in place, cfg 2's model
+  // runs 3.26 ms at d = 64 with 8 waves against 3.63-3.77 with 12, 4.00 against 4.63 at d = 96, 4.8 against 5.8 at d = 128)
   return SD_WAVES;
 #endif
 }

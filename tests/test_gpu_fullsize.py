@@ -162,9 +162,9 @@ def test_four_mode_reference_forms(gpu, d, B, kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,d", [("none", 96), ("none", 128), ("gaussian", 64), ("gmm", 48)])
 def test_three_wave_kernels_at_full_occupancy(gpu, kind, d):
-    """No reference + ClippedCtrl (every tile count), Gaussian / mixture reference up to four tiles: built for 12 waves per workgroup
-    (sim_kernel.hpp sd_waves_of).  40 000 particles = every wave slot busy, ragged last round: reruns and shards bit-equal, and blocks
-    of the big run -- one per wave slot -- equal a small launch of just that block."""
+    """No reference + ClippedCtrl: built for 12 waves per workgroup at every tile count (sim_kernel.hpp sd_waves_of); small Gaussian /
+    mixture references next to them (8 waves).  40 000 particles = every wave slot busy, ragged last round: reruns and shards
+    bit-equal, and blocks of the big run -- one per wave slot -- equal a small launch of just that block."""
     from sde_sampler_lrds_amd.distr.gauss import ManyModes
     from sde_sampler_lrds_amd.eq.sdes import VP, ScaledBM
     from sde_sampler_lrds_amd.losses import oc
