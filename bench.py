@@ -112,8 +112,9 @@ def roofline(cfg, info, B, N, k_ms, extra_flops=0):
          "traffic": None, "kernel_ms": k_ms, "algorithmic_flops_per_particle_step": flops_ps,
          "algorithmic_hbm_bytes_per_launch": (2 * info["d"] + 1) * 4 * B,  # x0 in (written by the sampler kernel), x_N and rnd out
          "note": "peak = dense FP32 MFMA/vector rate (an equivalence: results carry fp32 accuracy; the GEMMs are issued as a 3-product "
-                 "f16 split on v_mfma_f32_16x16x32_f16, 3x the algorithmic FLOP on the f16 pipe).  The binding resource is "
-                 "instruction issue: see `issue`."}
+                 "f16 split on v_mfma_f32_16x16x32_f16, 3x the algorithmic FLOP on the f16 pipe at 3/16 of the fp32 MFMA time -- so "
+                 "this fraction is not bounded by 1 and passes it once the vector work around the GEMMs is lean enough).  The binding "
+                 "resource is instruction issue: see `issue` (model and port utilisation) and `mfma_pipe`."}
     pj = os.path.join(ROOT, "profiles", f"r02_pmc_{cfg}.json")
     from sde_sampler_lrds_amd.experiments.baseline_configs import FULL_SIZE
     if os.path.exists(pj) and (B, N) == FULL_SIZE[cfg] and info.get("K", 4) == 4:
