@@ -40,8 +40,8 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   split_tiles<NT>(x, xh, xl);
   // From here to the end of the hidden layers the wave is in chains of dependent matrix instructions (score products, prior precision,
   // drift net): it wins issue arbitration against the other wave of its SIMD meanwhile (sim_kernel.hpp, same reason).  Measured on
-  // cfg 4, same box: 6.81 ms without, 6.61 around the hidden layers only, 6.47 from here.
-  __builtin_amdgcn_s_setprio(1);
+  // cfg 4, same box: 6.81 ms without, 6.61 around the hidden layers only, 6.47 from here (level 2; output layer, control and cost at 1).
+  __builtin_amdgcn_s_setprio(2);
 
   f32x4 ts[NT];
   if constexpr (TGT == CT_PHI4) {
@@ -122,7 +122,7 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
   // ---- control ----
   f32x4 hid[SD_HT];
   mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane);
-  __builtin_amdgcn_s_setprio(0);  // end of the matrix phase (raised at the top of this function)
+  __builtin_amdgcn_s_setprio(1);  // end of the matrix phase (raised at the top of this function); the rest of the step runs at 1
   const HidSplit hs = split_hidden(hid);
   const float st = s.stheta ? s.stheta[ki] : 1.0f;
 #pragma unroll
@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
             else w_s[t][r] = bg + u_t[t][r];
           }
       }
+      __builtin_amdgcn_s_setprio(0);  // noise and move of the next step at the lowest level (three levels: 6.49 -> 6.39 ms against two)
       c2 = group_sum(c2);
       cdb = group_sum(cdb);
       rnd += sgn * ((0.5f * c2) * dt);

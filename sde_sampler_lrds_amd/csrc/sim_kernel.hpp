@@ -224,10 +224,12 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       // The three hidden layers are one long chain of dependent matrix instructions: while a wave is in it, it wins the SIMD's issue
       // arbitration against the other wave(s), whose vector stream (noise, mixture score, tail) would otherwise be interleaved
       // between its MFMAs and stretch the chain.  Measured, same box: cfg 2 5.28 -> 4.70 ms, cfg 3 15.74 -> 14.84 ms; priority 1, 2
-      // and 3 are equal; raising it around the output-layer MFMAs of the tail as well is slightly worse (4.73 / 15.09).
-      __builtin_amdgcn_s_setprio(1);
+      // and 3 are equal; raising it around the output-layer MFMAs of the tail as well is slightly worse (4.73 / 15.09).  Three levels
+      // -- hidden layers 2, the whole tail (output layer, noise, integrator) 1, scores and bookkeeping 0 -- are worth another 2.4 %
+      // (4.74 -> 4.63, 15.22 -> 14.86): profiles/r02_issue_priority.log.
+      __builtin_amdgcn_s_setprio(2);
       mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
-      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(1);
       const HidSplit hs = split_hidden(hid);
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
@@ -520,6 +522,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
         if (t0 + 1 < NT) out_group(std::integral_constant<int, 2>{}, t0);
         else out_group(std::integral_constant<int, 1>{}, t0);
       }
+      __builtin_amdgcn_s_setprio(0);  // end of the tail
       if constexpr (ref_lds) {  // next step's table: every read of this step's copy has been consumed above
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < a.N) dma_table_to_lds(a.ref_tab + static_cast<size_t>(k + 1) * tab_floats, my_tab, tab_floats, lane);
