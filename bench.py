@@ -7,13 +7,15 @@ exponential integrator, 65 536 particles x 256 steps per GPU, FourierMLP drift n
 and the log-Z / ESS reduction (the window the reference times as eval/sample_time, solver/oc.py:148-158); the inputs are the
 seed and the model.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rds_gmm|pis_phi4|cmcd_logreg]
 
 For N>1 launch with torch.distributed.run (one rank per GPU, RCCL): the particle batch is sharded (weak scaling: 65 536 particles
 per rank), no collective inside the step loop, one 36-byte all-gather for the final log-Z / ESS.
 
 Prints ONE JSON line (rank 0): the contract keys for the headline workload, plus
-  roofline       FP32-equivalent matrix roof of the step-loop kernel AND its instruction-issue roof (`issue`), HBM traffic (PMC)
+  roofline       what binds the step-loop kernel: the SIMD vector-issue port (`bound: valu_issue`, frac = measured port-busy share, from the
+                 counter record of THIS library build) -- or, without such a record, the matrix pipe's live utilisation; plus the
+                 matrix-pipe (`mfma_pipe`) and FP32-equivalent (`fp32_equiv`) figures, the issue model (`issue`) and HBM traffic (PMC)
   cpu_baseline   the CPU oracle (a port of the reference's torch loop) on a bounded sample, host cores stated
   log_z_abs_err  |log Z_HIP - log Z_oracle| on a block of 2 048 particles with identical seeds (x0 and noise), outside every timed window
   other_configs  the same five items for configs[2] (PhiFour PIS, 131 072 x 512) and configs[3] (CMCD logistic regression, one GPU's
@@ -80,7 +82,12 @@ def oracle_leg(cfg, info, ts, hip_block, seed, N, cpu_budget_s, chunk):
     out["parity"] = {"block": f"particles [0, {hx.shape[0]}) x {N} steps, identical seeds (x0: Philox stream 1, noise: stream 0)",
                      "log_z_hip": lz_hip, "log_z_oracle": lz_orc,
                      "x_N_max_rel_err": float(((hx.cpu() - ox).abs() / ox.abs().clamp(min=1.0)).max()),
-                     "rnd_max_err_rel_to_largest_summand": float((hrnd.cpu().flatten() - ornd.flatten()).abs().max()) / scale}
+                     "rnd_max_err_rel_to_largest_summand": float((hrnd.cpu().flatten() - ornd.flatten()).abs().max()) / scale,
+                     # the plain figure next to it: log-weights are sums of terminal log-densities of magnitude `scale` that largely
+                     # cancel, so one fp32 ulp of a summand (scale x 6e-8) is already 1e-5 of a small |rnd|
+                     "rnd_max_rel_err_plain": float(((hrnd.cpu().flatten() - ornd.flatten()).abs() / ornd.flatten().abs().clamp(min=1e-30)).max()),
+                     "rnd_median_rel_err_plain": float(((hrnd.cpu().flatten() - ornd.flatten()).abs() / ornd.flatten().abs().clamp(min=1e-30)).median()),
+                     "rnd_largest_summand": scale}
     # (b) CPU baseline: torch's own generator for the noise, like the reference
     if cpu_budget_s > 0:
         d = info["d"]
@@ -103,54 +110,94 @@ def oracle_leg(cfg, info, ts, hip_block, seed, N, cpu_budget_s, chunk):
     return out
 
 
+def library_digest() -> str:
+    """Digest of the kernel sources + build flags the loaded libsdeng.so was built from (sde_sampler_lrds_amd/build.py)."""
+    from sde_sampler_lrds_amd import build as B
+    return B._digest()
+
+
+def pmc_record(cfg):
+    """The committed counter record of this workload's step-loop kernel -- only if it was collected with THIS build of the library
+    (``library_digest`` stamped by tools/pmc_passes.sh equals the digest of the sources here).  A kernel change without a PMC refresh
+    therefore drops the counter-derived fields from the line instead of quoting stale counters."""
+    import glob
+    dig = library_digest()
+    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{cfg}.json")), reverse=True):
+        j = json.load(open(pj))
+        if j.get("library_digest") == dig:
+            return j, os.path.relpath(pj, ROOT)
+    return None, None
+
+
+def mfma_per_tile_step(cfg, info):
+    """v_mfma_f32_16x16x32_f16 instructions one 16-particle tile issues per SDE step: 3 split products x (output tiles x K-blocks) of
+    every GEMM in the step (sim_device.hpp dense / dense_pre; cmcd_kernel.hpp).  Equals SQ_INSTS_MFMA / tile-steps of the PMC passes."""
+    nt = (info["d"] + 15) // 16
+    kb = (nt + 1) // 2
+    net = 3 * (4 * kb + 4 * 2 + 4 * 2 + nt * 2)
+    if cfg != "cmcd_logreg":
+        return net
+    n = info["X"].shape[0]
+    return net + 3 * (((n + 15) // 16) * kb + nt * ((n + 31) // 32) + nt * kb)  # + logits, gradient and prior-precision products
+
+
 def roofline(cfg, info, B, N, k_ms, extra_flops=0):
-    """FP32-equivalent matrix roof (algorithmic drift-net FLOP at the dense FP32 rate) and the instruction-issue roof of the
-    step-loop kernel, from the committed PMC counters of the same workload (profiles/r02_pmc_<cfg>.json, tools/pmc_passes.sh)."""
+    """What bounds the step-loop kernel, and how close it runs to that bound.
+
+    The kernel keeps the state on chip (HBM: 0.5 % of the per-step-launch traffic) and its GEMMs are small, so neither HBM nor the
+    matrix pipe binds: the SIMD's vector-instruction issue does.  Headline: ``bound = "valu_issue"``, ``frac`` = the measured share
+    of SIMD cycles in which the vector port is issuing (PMC, <= 1).  That needs the counter record of THIS library build
+    (``pmc_record``); without one the headline falls back to the matrix pipe's own utilisation, measured live: f16 FLOP issued
+    (split products included) over the dense f16 MFMA peak.  The FP32-equivalent figure of earlier rounds stays as a named
+    sub-field: it is an accounting equivalence, not a utilisation."""
     flops_ps = info["flops"] + extra_flops
-    achieved = flops_ps * B * N / (k_ms * 1e-3) / 1e12
-    r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+    tile_steps = ((B + 15) // 16) * N
+    fp32_equiv = flops_ps * B * N / (k_ms * 1e-3) / 1e12
+    issued = mfma_per_tile_step(cfg, info) * tile_steps * 16384.0 / (k_ms * 1e-3) / 1e12  # one 16x16x32 MFMA = 2*16*16*32 FLOP
+    r = {"bound": "mfma", "achieved": issued, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_F16_MFMA_TFLOPS,
          "traffic": None, "kernel_ms": k_ms, "algorithmic_flops_per_particle_step": flops_ps,
          "algorithmic_hbm_bytes_per_launch": (2 * info["d"] + 1) * 4 * B,  # x0 in (written by the sampler kernel), x_N and rnd out
-         "note": "peak = dense FP32 MFMA/vector rate (an equivalence: results carry fp32 accuracy; the GEMMs are issued as a 3-product "
-                 "f16 split on v_mfma_f32_16x16x32_f16, 3x the algorithmic FLOP on the f16 pipe at 3/16 of the fp32 MFMA time -- so "
-                 "this fraction is not bounded by 1 and passes it once the vector work around the GEMMs is lean enough).  The binding "
-                 "resource is instruction issue: see `issue` (model and port utilisation) and `mfma_pipe`."}
-    pj = os.path.join(ROOT, "profiles", f"r02_pmc_{cfg}.json")
+         "mfma_pipe": {"issued_tflops_f16": issued, "peak": PEAK_F16_MFMA_TFLOPS, "frac": issued / PEAK_F16_MFMA_TFLOPS,
+                       "mfma_per_tile_step": mfma_per_tile_step(cfg, info),
+                       "reading": "what the matrix pipe executes (three f16 split products per fp32 product) over the dense f16 MFMA peak, "
+                                  "from the kernel time measured in this run: the pipe idles while the vector instructions of the same SIMD issue"},
+         "fp32_equiv": {"tflops": fp32_equiv, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS, "ratio": fp32_equiv / PEAK_FP32_MFMA_TFLOPS,
+                        "reading": "algorithmic fp32 drift-net FLOP per second over the dense FP32 MFMA rate: an accounting equivalence (results "
+                                   "carry fp32 accuracy, the products run on the f16 pipe at 3/16 of an fp32 MFMA's time), NOT a utilisation -- "
+                                   "it is not bounded by 1"},
+         "note": "no counter record for this library build: headline = matrix-pipe utilisation measured live; run tools/pmc_passes.sh to "
+                 "add the vector-issue figures"}
     from sde_sampler_lrds_amd.experiments.baseline_configs import FULL_SIZE
-    if os.path.exists(pj) and (B, N) == FULL_SIZE[cfg] and info.get("K", 4) == 4:
-        j = json.load(open(pj))
-        c = j["counters_per_launch"]
-        if j.get("traffic"):
-            r["traffic"] = j["traffic"]["bytes"]
-            r["traffic_unit"] = "bytes/launch"
-            r["traffic_source"] = f"profiles/r02_pmc_{cfg}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-        tile_steps = ((B + 15) // 16) * N
-        fp = c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]
-        counts = {"fp32 fma/mul/add": fp, "transcendental": c["SQ_INSTS_VALU_TRANS_F32"], "int64 mad (Philox)": c["SQ_INSTS_VALU_INT64"],
-                  "int32 mul": c["SQ_INSTS_VALU_INT32"], "convert": c["SQ_INSTS_VALU_CVT"], "mfma 16x16x32 f16": c["SQ_INSTS_MFMA"]}
-        counts["other vector (logic, select, move, cross-lane)"] = max(0.0, c["SQ_INSTS_VALU"] - sum(counts.values()))
-        model_ms = sum(counts[k] * ISSUE_NS[k] for k in counts) / N_SIMD * 1e-6
-        issued = c["SQ_INSTS_MFMA"] * 16384.0 / (k_ms * 1e-3) / 1e12  # one v_mfma_f32_16x16x32_f16 = 2 * 16 * 16 * 32 FLOP
-        r["mfma_pipe"] = {"issued_tflops_f16": issued, "peak": PEAK_F16_MFMA_TFLOPS, "frac": issued / PEAK_F16_MFMA_TFLOPS,
-                          "reading": "what the matrix pipe itself executes (split products included) against the dense f16 MFMA peak: the "
-                                     "pipe idles most of the time because the vector instructions of the same SIMD (noise, activations, "
-                                     "operand splits, reference score) issue in the same slots.  `frac` above can pass 1 (cfg 4, whose likelihood "
-                                     "adds two GEMMs per step): three f16 products cost 3/16 of one fp32 MFMA, so the fp32-equivalent rate "
-                                     "is an accounting figure, not a ceiling of this pipe."}
-        wps = 3 if cfg == "pis_phi4" else 2  # waves per SIMD of the instantiation (sim_kernel.hpp sd_waves_of)
-        port = None
-        if "SQ_ACTIVE_INST_VALU" in c and c.get("SQ_WAVE_CYCLES"):
-            port = {"waves_per_simd": wps, "valu_port_busy": wps * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
-                    "reading": "share of a SIMD's cycles in which its vector port is issuing (vector + matrix instructions): "
-                               "waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, per-wave counters of the same PMC passes"}
-        r["issue"] = {"bound": "vector + matrix instruction issue per SIMD (they do not overlap on gfx950)", "port": port,
-                      "instr_per_tile_step": {k: v / tile_steps for k, v in counts.items()},
-                      "vector_instr_per_tile_step": c["SQ_INSTS_VALU"] / tile_steps, "issue_cost_ns": ISSUE_NS,
-                      "model_ms": model_ms, "kernel_ms": k_ms, "frac": model_ms / k_ms,
-                      "source": f"profiles/r02_pmc_{cfg}.json (SQ_INSTS_* per launch), profiles/r01_ubench_valu_cost.log (cost per class)",
-                      "reading": "model_ms = sum over classes of count x issue cost / 1024 SIMDs: the time the kernel's own instruction "
-                                 "stream needs at full issue rate; frac = share of the kernel time it explains (the rest: LDS / scalar "
-                                 "waits, branches).  Faster means fewer instructions."}
+    j, src = pmc_record(cfg) if ((B, N) == FULL_SIZE[cfg] and info.get("K", 4) == 4) else (None, None)
+    if j is None:
+        return r
+    c = j["counters_per_launch"]
+    if j.get("traffic"):
+        r["traffic"] = j["traffic"]["bytes"]
+        r["traffic_unit"] = "bytes/launch"
+        r["traffic_source"] = f"{src} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    fp = c["SQ_INSTS_VALU_FMA_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_ADD_F32"]
+    counts = {"fp32 fma/mul/add": fp, "transcendental": c["SQ_INSTS_VALU_TRANS_F32"], "int64 mad (Philox)": c["SQ_INSTS_VALU_INT64"],
+              "int32 mul": c["SQ_INSTS_VALU_INT32"], "convert": c["SQ_INSTS_VALU_CVT"], "mfma 16x16x32 f16": c["SQ_INSTS_MFMA"]}
+    counts["other vector (logic, select, move, cross-lane)"] = max(0.0, c["SQ_INSTS_VALU"] - sum(counts.values()))
+    model_ms = sum(counts[k] * ISSUE_NS[k] for k in counts) / N_SIMD * 1e-6
+    wps = int(j.get("waves_per_simd") or (3 if cfg == "pis_phi4" else 2))  # waves per SIMD of the instantiation (sim_kernel.hpp sd_waves_of)
+    r["issue"] = {"instr_per_tile_step": {k: v / tile_steps for k, v in counts.items()},
+                  "vector_instr_per_tile_step": c["SQ_INSTS_VALU"] / tile_steps, "issue_cost_ns": ISSUE_NS,
+                  "model_ms": model_ms, "model_frac_of_kernel": model_ms / k_ms, "source": f"{src} (SQ_INSTS_* per launch), "
+                  "profiles/r01_ubench_valu_cost.log (cost per class)",
+                  "reading": "model_ms = sum over classes of count x issue cost / 1024 SIMDs: the time the kernel's own instruction stream "
+                             "needs at full issue rate"}
+    for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"):
+        if k in c:
+            r["issue"][k] = c[k]
+    if "SQ_ACTIVE_INST_VALU" in c and c.get("SQ_WAVE_CYCLES"):
+        busy = min(1.0, wps * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"])
+        r.update(bound="valu_issue", achieved=busy, peak=1.0, unit="fraction of SIMD cycles with the vector-issue port busy", frac=busy,
+                 note=f"binding resource: vector-instruction issue per SIMD.  frac = waves per SIMD ({wps}) x SQ_ACTIVE_INST_VALU / "
+                      f"SQ_WAVE_CYCLES from {src}, counters of this library build (digest {j['library_digest'][:12]}); the kernel gets "
+                      "faster by issuing fewer vector instructions or by hiding them under its own MFMAs.  `mfma_pipe` and `fp32_equiv` are the "
+                      "matrix-side figures, measured live")
     return r
 
 
@@ -256,8 +303,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--particles", type=int, default=65536, help="per GPU (headline workload)")
-    ap.add_argument("--sde-steps", type=int, default=256)
+    ap.add_argument("--workload", choices=["rds_gmm", "pis_phi4", "cmcd_logreg"], default="rds_gmm",
+                    help="BASELINE.json configs[1] (headline, default) / configs[2] / configs[3]; honoured with --gpus N "
+                         "(cmcd_logreg at 4 ranks = BASELINE's 262 144 particles over 4 GPUs, 65 536 per rank)")
+    ap.add_argument("--particles", type=int, default=None, help="per GPU (default: the workload's BASELINE size)")
+    ap.add_argument("--sde-steps", type=int, default=None)
     ap.add_argument("--modes", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -276,32 +326,41 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    B, N = a.particles, a.sde_steps
-    head = measure("rds_gmm", device, B, N, a.steps, a.warmup, a.spinup, dist, rank, world, modes=a.modes)
+    from sde_sampler_lrds_amd.experiments.baseline_configs import FULL_SIZE
+    wl = a.workload
+    B, N = FULL_SIZE[wl]
+    if a.particles is not None:
+        B = a.particles
+    if a.sde_steps is not None:
+        N = a.sde_steps
+    head = measure(wl, device, B, N, a.steps, a.warmup, a.spinup, dist, rank, world, modes=a.modes)
     others = []
-    if world == 1 and not a.no_other_configs:
-        from sde_sampler_lrds_amd.experiments.baseline_configs import FULL_SIZE
+    if world == 1 and not a.no_other_configs and wl == "rds_gmm":
         for cfg in ("pis_phi4", "cmcd_logreg"):
             others.append(measure(cfg, device, *FULL_SIZE[cfg], a.steps, a.warmup, a.spinup, None, 0, 1))
     if rank == 0:
         with_cpu = world == 1 and not a.no_cpu_baseline
-        e = config_entry(head, 15.0, 8192, with_cpu)
+        chunks = {"rds_gmm": 8192, "pis_phi4": 4096, "cmcd_logreg": 2048}
+        e = config_entry(head, 15.0, chunks[wl], with_cpu)
+        desc = {"rds_gmm": f"ManyModes d=128 K={a.modes}, RDS gmm-ref, VP(0.1,10), EI integrator",
+                "pis_phi4": "PhiFour d=100, PIS target-informed drift, EM integrator",
+                "cmcd_logreg": "LogisticRegression d=61 (sonar-shaped synthetic design matrix), CMCD lv-loss sampler"}[wl]
         out = {
             "metric": "particle-steps/sec (batch*n_steps/wall) + log-Z abs-err vs ref", "value": head["value"], "unit": "particle-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ManyModes d=128 K={a.modes}, RDS gmm-ref, VP(0.1,10), EI integrator, "
-                                   f"{B} particles x {N} steps per GPU, FourierMLP(4x64) drift, x0 and noise drawn by the engine (Philox)",
-                       "particles_per_gpu": B, "sde_steps": N, "parallelism": f"particle-sharded x{world}"},
+            "config": {"workload": f"{desc}, {B} particles x {N} steps per GPU, FourierMLP(4x64) drift, x0 and noise drawn by the engine (Philox)",
+                       "name": wl, "particles_per_gpu": B, "sde_steps": N, "parallelism": f"particle-sharded x{world}"},
             "log_z_abs_err": e["log_z_abs_err"], "parity": e["parity"], "path": e["path"],
             "log_norm_const_is": e["log_norm_const_is"], "ess": e["ess"], "spinup_s": a.spinup, "roofline": e["roofline"],
+            "library_digest": library_digest(),
         }
         out["roofline"]["kernel"] = e["path"].split(":")[0] + " (one launch = all sde_steps of the batch)"
         if "cpu_baseline" in e:
             out["cpu_baseline"] = e["cpu_baseline"]
             out["speedup_vs_cpu"] = e["speedup_vs_cpu"]
         if others:
-            out["other_configs"] = [config_entry(m, 8.0, 4096 if m["cfg"] == "pis_phi4" else 2048, with_cpu) for m in others]
+            out["other_configs"] = [config_entry(m, 8.0, chunks[m["cfg"]], with_cpu) for m in others]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -94,6 +94,10 @@ extern "C" {
                                       to fp32 round-off, not bit for bit.  Honoured for ClippedCtrl, LIN / EM forms, no / Gaussian /
                                       small-mixture reference, d > 64, no noise_in (xs_out is written); ignored otherwise. */
 
+#define SDENG_FLAG_REMOVE_REF 32u  /* RemoveReferenceCtrl(score, ref_score, use_rescaling=False) (models/reparam.py:46-64): the control the loss sees is
+                                      ctrl(t, x) - ref_score(t, x), ref_score = the reference drift of `ref`.  Forward forms (LIN / EM) with a
+                                      Score / Lerp / CancelDrift control and a diagonal reference; SDENG_E_UNSUPPORTED otherwise. */
+
 /* ---- distributions (the distr package): log-density and score by hand-coded formulas ------------ */
 #define SDENG_DIST_NONE 0
 #define SDENG_DIST_GMM_DIAG 1   /* distr/gauss.py:138-244  GMM / TwoModes / ManyModes (MixtureSameFamily)   */
@@ -180,7 +184,8 @@ typedef struct sdeng_ref {
   const float* weights;    /* [k] unnormalised (normalised like distr/gauss.py:100)   */
   const float* eigvecs;    /* [k,d,d] GMM_FULL only, else NULL                        */
   int32_t shared_var;      /* GMM_DIAG: 1 = the caller guarantees that all k rows of vars_init are equal (the reference's default
-                              initialisation, variances_init = v * ones): mixtures with 4 < k <= 64 then run on the matrix pipe */
+                              initialisation, variances_init = v * ones): mixtures with 4 < k <= 64 then run on the matrix pipe.
+                              The promise is checked on the device: if the rows differ, x_out and rnd_out come back NaN. */
   int32_t reserved;
 } sdeng_ref;
 

@@ -45,11 +45,13 @@ def runner(cfg: str, info: dict, ts: torch.Tensor):
         loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
         refd = orc.GMMDiag(loc0, v0.sqrt(), w)
 
-        def run(x0, noise):
+        def run(x0, noise, return_traj=False):
             with torch.no_grad():
-                x, rnd, _ = orc.simulate_ei_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp,
-                                                lambda t, xx: orc.mog_score(xx, w, *sde.marginal_diag(t, means, var)), noise)
-                return x, rnd, max(1.0, float(tgt.logp(x).abs().max()))
+                x, rnd, xs = orc.simulate_ei_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp,
+                                                 lambda t, xx: orc.mog_score(xx, w, *sde.marginal_diag(t, means, var)), noise,
+                                                 return_traj=return_traj)
+                scale = max(1.0, float(tgt.logp(x).abs().max()))
+                return (x, rnd, scale, xs) if return_traj else (x, rnd, scale)
         return run
     if cfg == "pis_phi4":
         g, T, d = math.sqrt(0.2), 5.0, info["d"]

@@ -650,6 +650,19 @@ class Ctrl:
         raise ValueError(self.kind)
 
 
+class RemoveReference:
+    """models/reparam.py:46-64 RemoveReferenceCtrl in the form its forward can evaluate (``use_rescaling=False``):
+    ``ret = score(t, x); ret -= ref_score(t, x)``."""
+
+    def __init__(self, score, ref_score):
+        self.score, self.ref_score = score, ref_score
+
+    def __call__(self, t, x):
+        ret = self.score(t, x)
+        ret -= self.ref_score(t, x)
+        return ret
+
+
 # --------------------------------------------------------------------------- #
 # noise sources
 # --------------------------------------------------------------------------- #

@@ -245,6 +245,9 @@ __global__ void __launch_bounds__(256) k_ref_mm_tables(RefMMArgs a) {
       for (int j = 0; j < a.K; ++j) c += a.means[static_cast<size_t>(j) * a.d + f];
       c = S * (c / static_cast<float>(a.K));
       iv = 1.0f / (VA + S2 * a.vars[f]);
+      // sdeng_ref.shared_var is the caller's promise; k_same_var checked it on the device (no host round trip): a false promise
+      // poisons the table, so every score -- and the whole result -- is NaN instead of silently that of another mixture
+      if (a.same_var[0] == 0.0f) iv = __builtin_nanf("");
     }
     cbar[f] = c;
     ivs[f] = iv;
@@ -891,6 +894,7 @@ int sd_launch_ref_full_tables(const RefFullArgs& a, int N, hipStream_t s) {
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_ref_mm_tables(const RefMMArgs& a, int N, hipStream_t s) {
+  hipLaunchKernelGGL(k_same_var, dim3(1), dim3(128), 0, s, a.vars, a.K, a.d, a.same_var);
   hipLaunchKernelGGL(k_ref_mm_tables, dim3(N), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }

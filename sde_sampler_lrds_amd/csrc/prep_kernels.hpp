@@ -50,6 +50,7 @@ struct RefMMArgs {
   float* images;    // [N][kt*KB(NT)*512 + NT*KB(kt)*512]
   float* centre;    // [N][2][dpad]   centre of the noised means, 1/var (0 on pad features)
   float* consts;    // [N][64]        b_k = log w_k - 0.5 sum_f (mu_kf - c_f)^2 / var_f ; -inf on pad components
+  float* same_var;  // [1] scratch: k_same_var's verdict on `vars` -- a caller whose shared_var promise is false gets NaN, not a wrong score
 };
 
 struct DistTabArgs {

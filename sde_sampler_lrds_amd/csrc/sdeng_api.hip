@@ -493,6 +493,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
         r.K = K; r.d = d->d; r.dpad = dpad; r.NT = DT; r.kt = kt; r.coef = d->coef;
         r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = d->ref.weights;
         r.images = ws + L.ref_tab; r.centre = ws + L.ref_mean; r.consts = ws + L.ref_consts;
+        r.same_var = ws + L.ref_consts + static_cast<size_t>(d->N) * 64;  // the slot behind the per-step constants (make_layout: N * 64 + 1)
         SD_HIP(sd_launch_ref_mm_tables(r, d->N, s));
       }
       a.ref_k = K; a.ref_kc = kt;
@@ -577,6 +578,10 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   t.ref = ref_dist; t.target = target; t.use_ref = tr; t.use_target = tt;
   t.B = d->B; t.d = d->d; t.dpad = dpad;
 
+  if ((d->flags & SDENG_FLAG_REMOVE_REF) && (sc == SC_NONE || sc == SC_LOGREG || rf == RF_NONE || rf == RF_GMM_FULL || rf == RF_GMM_MM || d->form == SDENG_FORM_EUBO))
+    return fail(SDENG_E_UNSUPPORTED, "FLAG_REMOVE_REF (RemoveReferenceCtrl): forward forms with a Score / Lerp / CancelDrift control on a mixture or "
+                                     "phi^4 target and a diagonal Gaussian / mixture reference (ctrl_kind %d, ref.kind %d, form %d)",
+                d->net.ctrl_kind, d->ref.kind, d->form);
   sim_launch_fn fn;
   if (d->form == SDENG_FORM_EUBO) {
     if ((rf == RF_NONE) == (sc == SC_NONE))

@@ -449,6 +449,22 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       // ---- per pair of output tiles: out_layer (MFMA) -> clip -> cost -> noise -> integrator -> Ito term ----
       float su2 = 0.0f, suz = 0.0f, sux = 0.0f;
       // (NT odd: pairs, then the last tile alone -- `t0` is a constant after unrolling, the dead branch goes away)
+      constexpr bool can_remove = SC != SC_NONE && REF != RF_NONE && !eubo;
+      auto ref_tile = [&](int t) __attribute__((always_inline)) -> f32x4 {  // reference score of feature tile t
+        f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef SD_DBG_NOREF
+        if constexpr (REF == RF_GMM) rq = f32x4{resp[0], resp[0], resp[0], resp[0]};
+#else
+        if constexpr (REF == RF_GMM) {
+          if (kfast) rq = gmm_score_tile_centred<NT>(x, rtab, g, resp, t);  // the reference's default reference: one test
+          else if (kfull) rq = gmm_score_tile<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t);
+          else rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
+        }
+#endif
+        if constexpr (REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM) rq = rs[t];
+        if constexpr (REF == RF_GAUSS) rq = gauss_score_tile<NT>(x, rtab, g, t);
+        return rq;
+      };
       auto out_group = [&](auto otc, int t0) __attribute__((always_inline)) {
         constexpr int OT = decltype(otc)::value;
         f32x4 u[OT];
@@ -472,6 +488,14 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
         for (int o = 0; o < OT; ++o) {
           const int t = t0 + o;
           if constexpr (SC != SC_NONE) add_ctrl_score_tile(a, u[o], ts[t], x[t], st, score_gain, lerp_w, t, 4 * g, d_dyn);
+          f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};  // reference score of this tile
+          if constexpr (can_remove) {
+            // RemoveReferenceCtrl (models/reparam.py:46-64, use_rescaling = False): the control is ctrl - ref_score; the reference score of
+            // the tile is needed for the drift anyway, it is only formed before the running cost instead of after the noise.  Only in the
+            // instantiations with a score control AND a reference (upstream: "only used for Langevin init") -- the plain samplers carry no test.
+            rq = ref_tile(t);
+            if (a.flags & SDENG_FLAG_REMOVE_REF) u[o] = u[o] - rq;
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float uv = u[o][r];
@@ -480,18 +504,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
             if constexpr (!eubo) su2 = __builtin_fmaf(uv, uv, su2);
           }
           const f32x4 z = noise_tile(t);  // EUBO: the same counters as in the noising phase above, regenerated
-          f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};  // reference score of this tile
-#ifdef SD_DBG_NOREF
-          if constexpr (REF == RF_GMM) rq = f32x4{resp[0], resp[0], resp[0], resp[0]};
-#else
-          if constexpr (REF == RF_GMM) {
-            if (kfast) rq = gmm_score_tile_centred<NT>(x, rtab, g, resp, t);  // the reference's default reference: one test
-            else if (kfull) rq = gmm_score_tile<NT, SD_KREG>(x, rtab, SD_KREG, g, resp, t);
-            else rq = same_var ? gmm_score_tile_shared_var<NT>(x, rtab, a.ref_k, g, resp, t) : gmm_score_tile<NT>(x, rtab, a.ref_k, g, resp, t);
-          }
-#endif
-          if constexpr (REF == RF_GMM_BIG || REF == RF_GMM_FULL || REF == RF_GMM_MM) rq = rs[t];
-          if constexpr (REF == RF_GAUSS) rq = gauss_score_tile<NT>(x, rtab, g, t);
+          if constexpr (!can_remove) rq = ref_tile(t);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float xv = x[t][r], uv = u[o][r];

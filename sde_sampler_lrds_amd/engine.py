@@ -15,6 +15,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import math
+import weakref
 
 import torch
 
@@ -191,10 +192,27 @@ def _time_embed(te, device, keep) -> L.TimeEmbed:
     return out
 
 
-def net_desc(ctrl, device, keep) -> L.Net:
-    """ClippedCtrl / ScoreCtrl / LerpCtrl around FourierMLP(4 layers, 64 channels, GELU) -> sdeng_net."""
-    if _name(ctrl) == "AveragedModel":  # EMA wrapper (solver/oc.py:69-78)
+def unwrap_ctrl(ctrl):
+    """(control module the kernels know, RemoveReferenceCtrl wrapper or None).  Peels the EMA wrapper (``AveragedModel``,
+    solver/oc.py:69-78) and ``RemoveReferenceCtrl`` (models/reparam.py:46-64: ``score(t, x) - ref_score(t, x)``), which the step loop
+    applies as SDENG_FLAG_REMOVE_REF -- only in the form upstream's forward can evaluate (``use_rescaling=False``)."""
+    if _name(ctrl) == "AveragedModel":
         ctrl = ctrl.module
+    wrapper = None
+    if _name(ctrl) == "RemoveReferenceCtrl":
+        wrapper = ctrl
+        if ctrl.use_rescaling:
+            raise UnsupportedByEngine("RemoveReferenceCtrl(use_rescaling=True): upstream's forward needs the `sde` its constructor refuses "
+                                      "(models/reparam.py:52, :60) and raises AttributeError; use_rescaling=False is on the HIP path")
+        ctrl = ctrl.score
+        if _name(ctrl) == "AveragedModel":
+            ctrl = ctrl.module
+    return ctrl, wrapper
+
+
+def net_desc(ctrl, device, keep) -> L.Net:
+    """ClippedCtrl / ScoreCtrl / LerpCtrl / CancelDriftCtrl around FourierMLP(4 layers, 64 channels, GELU) -> sdeng_net."""
+    ctrl, _ = unwrap_ctrl(ctrl)
     kinds = {"ClippedCtrl": L.CTRL_CLIPPED, "ScoreCtrl": L.CTRL_SCORE, "LerpCtrl": L.CTRL_LERP, "CancelDriftCtrl": L.CTRL_CANCEL_DRIFT}
     if _name(ctrl) not in kinds:
         raise UnsupportedByEngine(f"control wrapper {_name(ctrl)} has no HIP kernel")
@@ -223,8 +241,7 @@ def net_desc(ctrl, device, keep) -> L.Net:
 
 def ctrl_target(ctrl):
     """Distribution whose score ScoreCtrl/LerpCtrl mixes in (``target_score`` is a bound ``Distribution.score``)."""
-    if _name(ctrl) == "AveragedModel":
-        ctrl = ctrl.module
+    ctrl, _ = unwrap_ctrl(ctrl)
     if _name(ctrl) == "ClippedCtrl":
         return None, None
     tgt = _self_of(ctrl.target_score)
@@ -258,6 +275,46 @@ def resolve_reference(reference_ctrl):
     raise UnsupportedByEngine("EBM ('nn') references need autograd inside the step: not on the HIP path")
 
 
+class _TensorCache:
+    """Derived facts about a caller's tensor (shared-variance test, eigendecomposition), keyed by the tensor OBJECT: the entry holds a
+    weak reference, so it dies with the tensor and a new tensor the allocator places at the same address can never match; the
+    (version, shape, device) part of the key catches in-place edits.  Nothing is ever written into the caller's own containers
+    (``reference_distr_utils`` is iterated by ``RDS.state_dict()`` and ``MarginalReference.to()``)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, t: torch.Tensor, compute):
+        key = (t._version, tuple(t.shape), str(t.device), t.data_ptr())
+        hit = self._d.get(id(t))
+        if hit is not None and hit[0]() is t and hit[1] == key:
+            return hit[2]
+        val = compute(t)
+        ident = id(t)
+        self._d[ident] = (weakref.ref(t, lambda _r, i=ident: self._d.pop(i, None)), key, val)
+        return val
+
+
+_SHARED_VAR = _TensorCache()
+_EIGH = _TensorCache()
+
+
+def same_reference(a, b) -> bool:
+    """Do two ``reference_distr_utils`` dicts describe the same reference (same tensors, or equal contents)?"""
+    if a is b:
+        return True
+    if not isinstance(a, dict) or not isinstance(b, dict) or a.keys() != b.keys():
+        return False
+    for k in a:
+        va, vb = (a[k] if isinstance(a[k], tuple) else (a[k],)), (b[k] if isinstance(b[k], tuple) else (b[k],))
+        if len(va) != len(vb):
+            return False
+        for x, y in zip(va, vb):
+            if x is not y and not (x.shape == y.shape and torch.equal(x.detach().cpu(), y.detach().cpu())):
+                return False
+    return True
+
+
 def ref_desc(kind, utils, device, keep) -> L.Ref:
     r = L.Ref()
     if kind == "none":
@@ -283,29 +340,16 @@ def ref_desc(kind, utils, device, keep) -> L.Ref:
             if isinstance(var, tuple):
                 evals, evecs = var
             else:
-                # cached on the owning utils dict; the entry keeps `var` itself alive, so the (address, version) key cannot be
-                # matched by another tensor that the allocator later places at the same address
-                key = (var.data_ptr(), var._version, tuple(var.shape), str(var.device))
-                hit = utils.get("_sdeng_eigh") if isinstance(utils, dict) else None
-                if hit is None or hit[0] != key or hit[2] is not var:
-                    hit = (key, torch.linalg.eigh(var.detach().double()), var)
-                    if isinstance(utils, dict):
-                        utils["_sdeng_eigh"] = hit
-                evals, evecs = hit[1][0].float(), hit[1][1].float()
+                eig = _EIGH.get(var, lambda v: torch.linalg.eigh(v.detach().double()))  # once per parameter version
+                evals, evecs = eig[0].float(), eig[1].float()
             r.kind = L.REF_GMM_FULL
             r.vars_init = _dev_f32(evals, device, keep)
             r.eigvecs = _dev_f32(evecs, device, keep)
         else:
             r.kind = L.REF_GMM_DIAG
             r.vars_init = _dev_f32(var, device, keep)
-            # do all components share one variance vector?  (one read-back per parameter version; the entry keeps `var` alive)
-            key = (var.data_ptr(), var._version, tuple(var.shape), str(var.device))
-            hit = utils.get("_sdeng_shared_var") if isinstance(utils, dict) else None
-            if hit is None or hit[0] != key or hit[2] is not var:
-                hit = (key, bool(torch.equal(var, var[:1].expand_as(var))), var)
-                if isinstance(utils, dict):
-                    utils["_sdeng_shared_var"] = hit
-            r.shared_var = 1 if hit[1] else 0
+            # do all components share one variance vector?  (one read-back per parameter version)
+            r.shared_var = 1 if _SHARED_VAR.get(var, lambda v: bool(torch.equal(v, v[:1].expand_as(v)))) else 0
     return r
 
 

@@ -13,12 +13,15 @@ from ..distr.gauss import BracketTwoModes, ManyModes, TwoModes, TwoModesFull
 from ..distr.logistic_regression import LogisticRegression
 from ..distr.phi_four import PhiFour
 from ..distr.rings import Rings
+from ..engine import UnsupportedByEngine
+from ..models.reparam import RemoveReferenceCtrl
 from ..solver import oc
 from ..utils.common import get_timesteps
 
 solver_types = {"dds_orig": "dds", "pis_orig": "pis", "dis_orig": "dis", "cmcd": "cmcd", "vp-ref": "vp_rds", "pbm-ref": "pbm_rds"}
-model_types = {"target_informed_zero_init": "score", "target_informed_lerp_tempering": "lerp", "base_zero_init": "basic",
-               "target_informed_langevin_init": "langevin_init"}
+model_types = {"target_informed_zero_init": "score", "target_informed_unet_zero_init": "score_unet",
+               "target_informed_langevin_init": "langevin_init", "target_informed_lerp_tempering": "lerp", "base_zero_init": "basic",
+               "unet_zero_init": "basic_unet"}
 
 # conf/solver/*.yaml -> (solver class, prior, sde, default model, default loss)
 _SOLVERS = {
@@ -57,7 +60,7 @@ def make_target_details(target_name, **kwargs):
         return dict(name="rings")
     if target_name in LOGREG_TARGETS:  # benchmark_utils.py:84-91
         return dict(name=target_name)
-    raise NotImplementedError(f"Target {target_name} not supported by the HIP engine.")
+    raise UnsupportedByEngine(f"Target {target_name} has no HIP log-density / score kernel.")
 
 
 def _make_target(details):
@@ -82,25 +85,81 @@ def _make_target(details):
     raise NotImplementedError(name)
 
 
+def validate_make_model_args(solver_type, ref_type, loss_type, integrator_type, model_type, time_type, solver_details=None,
+                             target_details=None, training_details=None, force_base_zero_init=False, force_vp20=False,
+                             force_vp_cosine=False):
+    """The argument checks of the reference's ``make_model`` (experiments/benchmark_utils.py:100-160), in its order, with its
+    exception types and messages: the same combinations are rejected, for the same stated reason.  ``tests/golden/make_model_grid.json``
+    holds the outcome of the reference's own lines for the whole (solver x ref x loss x integrator x model x time x force_*) grid;
+    ``tests/test_make_model_contract.py`` compares this function with it entry by entry."""
+    # :101-109
+    assert solver_type in solver_types
+    assert ref_type in ["default", "gaussian", "gmm", "nn"]
+    assert loss_type in ["kl", "lv"]
+    assert integrator_type in ["em", "ei", "ddpm_like"]
+    assert model_type in model_types
+    assert time_type in ["uniform", "snr"]
+    if solver_details is not None:
+        assert isinstance(solver_details, dict)
+    if target_details is not None:
+        assert isinstance(target_details, dict) and ("name" in target_details)
+    if training_details is not None:
+        assert isinstance(training_details, dict)
+    zero_init_models = ["target_informed_zero_init", "target_informed_unet_zero_init"]
+    # :112-131 the original samplers (PIS / DDS / DIS) and CMCD
+    if ("orig" in solver_type) or ("dis" in solver_type) or ("cmcd" in solver_type):
+        if not ((model_type == "base_zero_init") and force_base_zero_init):
+            if (solver_type == "dds_orig") and (model_type not in zero_init_models):
+                raise ValueError("Only target_informed_zero_init model is supported.")
+            if (solver_type == "pis_orig") and (model_type not in zero_init_models):
+                raise ValueError("Only target_informed_zero_init model is supported.")
+            if ("dis" in solver_type) and (model_type == "base_zero_init"):
+                raise ValueError("Model base_zero_init is not supported.")
+            if (solver_type == "cmcd") and (model_type == "base_zero_init"):  # (the upstream message says the opposite of the test)
+                raise ValueError("Only base_zero_init is supported for CMCD.")
+        if not (time_type == "uniform"):
+            raise ValueError("Only uniform time discretisation is supported for orig/cmcd models.")
+        if not (integrator_type == "em"):
+            raise ValueError("Can't use EI or DDPM-like discretization with orig models.")
+        if force_vp20 and (solver_type != "dis_orig"):
+            raise ValueError("Can't use vp_20 for orig models other than DIS.")
+        if force_vp_cosine:
+            raise ValueError("Can't use vp_cosine for orig models.")
+    # :134-144 the reference-based samplers
+    if "ref" in solver_type:
+        if model_type == "target_informed_lerp_tempering":
+            raise ValueError("Model target_informed_lerp_tempering is not supported.")
+        if (solver_type == "pbm-ref") and (time_type == "uniform"):
+            raise ValueError("PBM schedule is unstable with uniform time discretization.")
+        if (integrator_type == "ddpm_like") and (time_type == "uniform"):
+            raise ValueError("Using the integration scheme from DDPM with uniform times is unstable.")
+    # :147-150
+    if force_vp20 and force_vp_cosine:
+        raise ValueError("Can't use vp_20 and vp_cosine at the same time.")
+    if (solver_type == "pbm-ref") and (force_vp20 or force_vp_cosine):
+        raise ValueError("Can't use vp_20 or vp_cosine with PBM.")
+    # :153-156
+    if ((ref_type != "default") and ("ref" not in solver_type)) and (solver_type != "cmcd"):
+        raise ValueError("Only ref models can use a non-default ref.")
+    if (solver_type == "cmcd") and (ref_type not in ["default", "gaussian"]):
+        raise ValueError("Can't use ref other than gaussian for CMCD.")
+    # :159-160
+    if (model_type == "target_informed_langevin_init") and (integrator_type in ["ei", "ddpm_like"]):
+        raise ValueError("Can't use EI or DDPM-like with Langevin score.")
+
+
 def make_model(solver_type, ref_type, loss_type, integrator_type, model_type, time_type, solver_details, target_details,
                training_details, optim_details=None, n_steps=100, force_base_zero_init=False, use_ema=False, force_vp20=False,
                force_vp_cosine=False, compute_samples_based_metrics=True, force_T_cosine=None, device="cuda"):
-    assert solver_type in solver_types and ref_type in ["default", "gaussian", "gmm", "nn"]
-    assert loss_type in ["kl", "lv"] and integrator_type in ["em", "ei", "ddpm_like"] and time_type in ["uniform", "snr"]
-    if model_type not in model_types:
-        raise NotImplementedError(f"model_type {model_type} has no HIP kernel")
-    orig = ("orig" in solver_type) or ("cmcd" in solver_type)
-    if orig and (time_type != "uniform" or integrator_type != "em"):
-        raise ValueError("orig/cmcd solvers: uniform times and the EM integrator only.")
-    if "ref" in solver_type:
-        if solver_type == "pbm-ref" and time_type == "uniform":
-            raise ValueError("PBM schedule is unstable with uniform time discretization.")
-        if integrator_type == "ddpm_like" and time_type == "uniform":
-            raise ValueError("Using the integration scheme from DDPM with uniform times is unstable.")
-    if ref_type != "default" and "ref" not in solver_type and solver_type != "cmcd":
-        raise ValueError("Only ref models can use a non-default ref.")
-    if ref_type == "nn":
-        raise NotImplementedError("'nn' references need autograd per step: no HIP kernel")
+    """experiments/benchmark_utils.py:96-265.  Every combination the reference rejects is rejected here with the same exception
+    (``validate_make_model_args``); of those it accepts, the ones without a HIP kernel -- UNet drift nets, 'nn' references -- raise
+    ``UnsupportedByEngine`` (a NotImplementedError) AFTER that validation, never a silently different sampler."""
+    validate_make_model_args(solver_type, ref_type, loss_type, integrator_type, model_type, time_type, solver_details, target_details,
+                             training_details, force_base_zero_init, force_vp20, force_vp_cosine)
+    if model_types[model_type] in ("score_unet", "basic_unet"):
+        raise UnsupportedByEngine(f"model_type {model_type}: the UNet drift net (models/mnist_unet.py) has no HIP kernel")
+    if ref_type == "nn" and "ref" in solver_type:
+        raise UnsupportedByEngine("'nn' references need autograd of an energy net inside every step (models/reparam.py:478-482): no HIP kernel")
 
     cls, prior, sde, loss_kind = _SOLVERS[solver_types[solver_type]]
     prior, sde = dict(prior), (dict(sde) if sde else None)
@@ -148,6 +207,13 @@ def make_model(solver_type, ref_type, loss_type, integrator_type, model_type, ti
     if time_type == "snr":
         model.train_timesteps = partial(get_timesteps, **model.train_timesteps.keywords, sde=model.sde)
         model.eval_timesteps = model.train_timesteps
+    # benchmark_utils.py:260-262.  Upstream this rebinds ``model.generative_ctrl`` AFTER the loss was built (solver/oc.py:504-511 hands the
+    # loss the control object at construction), so the loss -- every simulate / eval / training call -- keeps driving the un-wrapped
+    # CancelDriftCtrl; the wrapper only changes what ``model.generative_ctrl`` / ``state_dict()['generative_ctrl']`` (keys gain a
+    # ``score.`` prefix) and the EMA update see.  Reproduced as is: same object graph, same sampler.  (Called directly, the wrapper built
+    # with upstream's defaults -- use_rescaling=True, sde=None -- raises AttributeError there and here, models/reparam.py:58-60.)
+    if model_type == "target_informed_langevin_init" and "ref" in solver_type:
+        model.generative_ctrl = RemoveReferenceCtrl(model.generative_ctrl, model.reference_score_t).to(model.device)
     return model
 
 

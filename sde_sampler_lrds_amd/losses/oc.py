@@ -106,7 +106,7 @@ class BaseOCLoss:
         self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
         self.graph_training = False  # True: the batched control pass of log-variance training (forward + backward) is replayed as a hipGraph (_IntegralPass)
         self._graphed = {}
-        self.split_tiles = False  # True: small batches (<= 16 384) ask for the low-latency kernels (SDENG_FLAG_SPLIT_TILES; fp32-round-off, not bit, equal)
+        self.split_tiles = False  # True: small batches (<= _lib.SPLIT_TILES_MAX_B = 8 192, the library's own gate) ask for the low-latency kernels (SDENG_FLAG_SPLIT_TILES; fp32-round-off, not bit, equal to the standard kernel); the solvers switch it on (cfg 'split_tiles', default True)
         self.dist = None  # torch.distributed of a sharded run: eval() then returns global estimators and globally normalised weights
 
     # ---- reference surface -----------------------------------------------------------------
@@ -186,14 +186,14 @@ class BaseOCLoss:
         if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
             raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built "
                                         "(every conf/loss/*.yaml leaves both empty; listed under 'raises' in INTEGRATION.md)")
-        x = self._x0(x)
+        # a fresh stream per training call (the reference consumes torch's global generator): call c uses the engine's Philox
+        # streams keyed by seed + c * golden-ratio increment -- for the step noise AND for an x0 left to the engine (an InitialDraw
+        # materialised with the loss's fixed seed would hand every training step the same batch); call 0 is the eval stream of ``seed``
+        seed_c = self._next_train_seed()
+        x = self._x0(x, seed_c)
         if self.traj_per_sample != 1:
             x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
         N, (B, d) = ts.numel() - 1, x.shape
-        # a fresh noise stream per training call (the reference consumes torch's global generator): call c uses the
-        # engine's Philox stream keyed by seed + c * golden-ratio increment; call 0 is the eval stream of ``seed``
-        seed_c = (int(self.seed) + 0x9E3779B97F4A7C15 * self.train_calls) & 0xFFFFFFFFFFFFFFFF
-        self.train_calls += 1
         z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)
         # VALUE: the step loop already integrates exactly this rnd (the detached control is the control), terminal terms included.
         # (the kernel draws the normals of stream seed_c itself -- bit for bit the z above -- so nothing is injected and small
@@ -221,7 +221,9 @@ class BaseOCLoss:
         """The batched control pass, eager or -- ``graph_training`` -- as a captured graph per (shape, control): at the reference's
         training sizes the ~150 small kernels of its forward + backward are host-launch bound (tools/probe_training.py).  Only for the
         pure-torch controls (ClippedCtrl over a FourierMLP); anything else, or a capture that fails, runs eagerly."""
-        ctrl = self.generative_ctrl
+        # RemoveReferenceCtrl: u = inner - ref_score and ref_score has no parameters, so s - s.detach() of the inner control carries the
+        # same (zero) value and the same gradient
+        ctrl = E.unwrap_ctrl(self.generative_ctrl)[0] if type(self.generative_ctrl).__name__ == "RemoveReferenceCtrl" else self.generative_ctrl
         key = (id(ctrl), tuple(xs.shape), str(xs.device))
         fn = self._graphed.get(key)
         if fn is None:
@@ -255,10 +257,15 @@ class BaseOCLoss:
     def _ctrl(self, use_ema):
         return self.generative_ctrl_ema if use_ema else self.generative_ctrl
 
-    def _x0(self, x):
-        """``x`` as a tensor: an ``engine.InitialDraw`` (x0 left to the engine) is materialised with this loss's seed and shard
-        offset -- the same x0 sdeng_simulate draws itself when handed an InitialDraw."""
-        return x.tensor(self.seed, self.particle0) if isinstance(x, E.InitialDraw) else x
+    def _x0(self, x, seed=None):
+        """``x`` as a tensor: an ``engine.InitialDraw`` (x0 left to the engine) is materialised with this loss's seed (a training call:
+        that call's seed) and shard offset -- the same x0 sdeng_simulate draws itself when handed an InitialDraw."""
+        return x.tensor(self.seed if seed is None else seed, self.particle0) if isinstance(x, E.InitialDraw) else x
+
+    def _next_train_seed(self):
+        seed_c = (int(self.seed) + 0x9E3779B97F4A7C15 * self.train_calls) & 0xFFFFFFFFFFFFFFFF
+        self.train_calls += 1
+        return seed_c
 
     def _sde_cpu(self):
         """CPU copy of the SDE for the per-step scalar tables, rebuilt when a buffer of the SDE changes (load_state_dict, edits)."""
@@ -270,7 +277,7 @@ class BaseOCLoss:
 
     def _coef(self, ts, device, **kw):
         # per-step gains of the control wrapper itself (LerpCtrl: g(t) and t/T; CancelDriftCtrl: drift/g and g/2), whatever the loss
-        ctrl = getattr(self.generative_ctrl, "module", self.generative_ctrl)
+        ctrl, _ = E.unwrap_ctrl(self.generative_ctrl)
         cname = type(ctrl).__name__
         if cname in ("LerpCtrl", "CancelDriftCtrl") and kw.get("kind", self.kind) not in ("cmcd", "cmcd_eubo"):
             if cname == "LerpCtrl":
@@ -349,13 +356,19 @@ class BaseOCLoss:
         keep = []
         desc = L.Desc()
         desc.form = form
-        desc.flags = flags | (L.FLAG_SPLIT_TILES if self.split_tiles and x.shape[0] <= 16384 else 0)
+        desc.flags = flags | (L.FLAG_SPLIT_TILES if self.split_tiles and x.shape[0] <= L.SPLIT_TILES_MAX_B else 0)
         desc.N = ts.numel() - 1
         desc.seed = int(self.seed)
         desc.particle0 = int(self.particle0)
         ctrl = self._ctrl(use_ema)
         desc.net = E.net_desc(ctrl, device, keep)
         desc.ref = E.ref_desc(ref[0], ref[1], device, keep)
+        _, remove = E.unwrap_ctrl(ctrl)
+        if remove is not None:  # RemoveReferenceCtrl: u = ctrl - ref_score, with the reference score the step loop already evaluates
+            if ref[0] == "none" or not E.same_reference(E.resolve_reference(remove.ref_score)[1], ref[1]):
+                raise E.UnsupportedByEngine("RemoveReferenceCtrl.ref_score must be the loss's own reference_ctrl (the kernel subtracts the "
+                                            "reference score it evaluates for the drift)")
+            desc.flags |= L.FLAG_REMOVE_REF
         late = self._terminal(desc, keep, device, terminal_unnorm_log_prob, reference_log_prob)
         _, lerp_prior = E.ctrl_target(ctrl)
         rnd0 = None
@@ -547,12 +560,11 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
             raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
         if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
             raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control: not built")
-        x = self._x0(x)
+        seed_c = self._next_train_seed()
+        x = self._x0(x, seed_c)
         if self.traj_per_sample != 1:
             x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
         N, (B, d) = ts.numel() - 1, x.shape
-        seed_c = (int(self.seed) + 0x9E3779B97F4A7C15 * self.train_calls) & 0xFFFFFFFFFFFFFFFF
-        self.train_calls += 1
         z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)
         target = getattr(self.sde.target_score, "__self__", None)
         prior = getattr(self.sde.prior_score, "__self__", None)

@@ -1,4 +1,4 @@
-"""Control wrappers (mirror of ``sde_sampler/models/reparam.py``: ClippedCtrl :18-43, ScoreCtrl :63-117,
+"""Control wrappers (mirror of ``sde_sampler/models/reparam.py``: ClippedCtrl :18-43, RemoveReferenceCtrl :46-64, ScoreCtrl :67-117, CancelDriftCtrl :120-145,
 LerpCtrl :148-199).  See models/mlp.py for how these relate to the HIP path."""
 from __future__ import annotations
 
@@ -22,6 +22,26 @@ class ClippedCtrl(Module):
 
     def forward(self, t, x):
         return self.clipped_base_model(t, x)
+
+
+class RemoveReferenceCtrl(Module):
+    """models/reparam.py:46-64: ``score(t, x) - ref_score(t, x)`` (``use_rescaling=False``) or ``- sde.diff(t, x) * ref_score(t, x)``
+    (``use_rescaling=True``; upstream's constructor then forbids passing the ``sde`` its forward needs, so that branch raises
+    AttributeError when called -- kept).  "Only used for Langevin init", i.e. around a CancelDriftCtrl.  The step-loop kernel runs the
+    ``use_rescaling=False`` form as a control modifier (SDENG_FLAG_REMOVE_REF: u -= reference score, which the tail already holds)."""
+
+    def __init__(self, score, ref_score, use_rescaling=True, sde=None):
+        super().__init__()
+        assert not (use_rescaling and (sde is not None))
+        self.score, self.ref_score, self.use_rescaling, self.sde = score, ref_score, use_rescaling, sde
+
+    def forward(self, t, x):
+        ret = self.score(t, x)
+        if self.use_rescaling:
+            ret -= self.sde.diff(t, x) * self.ref_score(t, x)
+        else:
+            ret -= self.ref_score(t, x)
+        return ret
 
 
 class ScoreCtrl(ClippedCtrl):

@@ -13,7 +13,7 @@ from sde_sampler_lrds_amd.distr.rings import Rings
 from sde_sampler_lrds_amd.eq.sdes import VP, ControlledLangevinSDE, ControlledSDE, LangevinSDE, PinnedBM, ScaledBM
 from sde_sampler_lrds_amd.losses import oc
 from sde_sampler_lrds_amd.models.mlp import FourierMLP, TimeEmbed
-from sde_sampler_lrds_amd.models.reparam import CancelDriftCtrl, ClippedCtrl, LerpCtrl, ScoreCtrl
+from sde_sampler_lrds_amd.models.reparam import CancelDriftCtrl, ClippedCtrl, LerpCtrl, RemoveReferenceCtrl, ScoreCtrl
 from sde_sampler_lrds_amd.reference import MarginalReference
 
 
@@ -46,6 +46,9 @@ def build(c, device):
         sde = make_sde(m)
         target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
         ctrl = ClippedCtrl(base_model=_mlp(d), clip_model=m["clip_model"])
+        if m.get("remove_ref"):
+            ctrl = CancelDriftCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                                   clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"], sde=sde)
         ctrl.load_state_dict(c.params("ctrl."))
         if kind == "rds_gmm":
             cov_kind = m.get("cov", "diag")
@@ -57,6 +60,8 @@ def build(c, device):
         mods = [sde, target, ctrl, ref]
         for mod in mods:
             mod.to(device)
+        if m.get("remove_ref"):
+            ctrl = RemoveReferenceCtrl(ctrl, ref, use_rescaling=False)
         loss = cls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref)
         out.update(loss=loss, args=(target.unnorm_log_prob, ref.reference_distr.to(device).log_prob), kwargs={})
     elif kind == "pis_phi4":

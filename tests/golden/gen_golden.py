@@ -136,7 +136,7 @@ def pack_params(prefix, state):
 
 
 # ----------------------------------------------------------------------------- cases
-def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", beta_max=10.0, t_end=None, cov="diag"):
+def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", beta_max=10.0, t_end=None, cov="diag", remove_ref=False):
     """RDS with a diagonal-GMM reference (solver/oc.py:563-576), VP noising, basic model
     (conf/solver/vp_rds.yaml, conf/model/basic.yaml)."""
     torch.manual_seed(seed)
@@ -144,6 +144,9 @@ def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", b
     target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0,
                                n_reference_samples=10)
     ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
+    if remove_ref:  # Langevin init on a reference solver: CancelDriftCtrl (conf/model/langevin_init.yaml) under RemoveReferenceCtrl (below)
+        ctrl = r_rep.CancelDriftCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0), target_score=target.score,
+                                     detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0, sde=sde, langevin_init=True)
     means = target.loc.clone() + 0.1 * torch.randn(K, d)
     variances = 0.5 * torch.ones(K, d) * (1.0 + 0.2 * torch.rand(K, d))
     weights = torch.ones(K)
@@ -162,6 +165,9 @@ def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", b
     ref_ctrl = lambda t, x: sde.marginal_gmm_score(t=t, x=x, **ref_utils)  # noqa: E731
     cls = {"ei": r_oc.EIReferenceSDELoss, "ddpm_like": r_oc.DDPMLikeReferenceSDELoss,
            "em": r_oc.EMReferenceSDELoss}[integrator]
+    inner = ctrl
+    if remove_ref:  # models/reparam.py:46-64 in the form its forward can evaluate (use_rescaling=False): ctrl - ref_score
+        ctrl = r_rep.RemoveReferenceCtrl(inner, ref_ctrl, use_rescaling=False)
     loss = cls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref_ctrl)
     if time_type == "snr":
         ts = r_get_timesteps(1e-4, 1.0 - 1e-4, steps=N, sde=sde)
@@ -180,9 +186,11 @@ def case_rds_gmm(name, d, K, B, N, seed, integrator="ei", time_type="uniform", b
             ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=ref_distr.log_prob))
     meta = dict(kind="rds_gmm", integrator=integrator, d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=beta_max,
                 sigma=1.0, T=1.0, clip_model=1e4, time_type=time_type, cov=cov)
+    if remove_ref:
+        meta.update(remove_ref=True, clip_score=1e4, scale_score=1.0)
     arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], u0=u0, ref0=r0,
                   tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights,
-                  ref_means=means, ref_w=weights, **cov_arrays, **pack_params("ctrl.", sd(ctrl)))
+                  ref_means=means, ref_w=weights, **cov_arrays, **pack_params("ctrl.", sd(inner)))
     finish(name, meta, arrays, res, draws)
 
 
@@ -193,6 +201,9 @@ def case_eubo_gmm(name, d, K, B, N, seed, integrator, cov="diag"):
     sde = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0)
     target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
     ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
+    if remove_ref:  # Langevin init on a reference solver: CancelDriftCtrl (conf/model/langevin_init.yaml) under RemoveReferenceCtrl (below)
+        ctrl = r_rep.CancelDriftCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0), target_score=target.score,
+                                     detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0, sde=sde, langevin_init=True)
     means = target.loc.clone() + 0.1 * torch.randn(K, d)
     variances, weights = 0.5 * torch.ones(K, d), torch.ones(K)
     cov_arrays = dict(ref_vars=variances)
@@ -251,6 +262,9 @@ def case_train_lv(name, d, K, B, N, seed, integrator):
     sde = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0)
     target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
     ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
+    if remove_ref:  # Langevin init on a reference solver: CancelDriftCtrl (conf/model/langevin_init.yaml) under RemoveReferenceCtrl (below)
+        ctrl = r_rep.CancelDriftCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0), target_score=target.score,
+                                     detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0, sde=sde, langevin_init=True)
     means = target.loc.clone() + 0.1 * torch.randn(K, d)
     variances, weights = 0.5 * torch.ones(K, d), torch.ones(K)
 
@@ -405,6 +419,9 @@ def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em", ful
     ref_ctrl = lambda t, x: sde.marginal_score(t=t, x=x, x_init=x_init, var_init=var_init)  # noqa: E731
     cls = {"ei": r_oc.EIReferenceSDELoss, "ddpm_like": r_oc.DDPMLikeReferenceSDELoss,
            "em": r_oc.EMReferenceSDELoss}[integrator]
+    inner = ctrl
+    if remove_ref:  # models/reparam.py:46-64 in the form its forward can evaluate (use_rescaling=False): ctrl - ref_score
+        ctrl = r_rep.RemoveReferenceCtrl(inner, ref_ctrl, use_rescaling=False)
     loss = cls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref_ctrl)
     res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob,
                                                          compute_weights=True, return_traj=True, use_ema=False))
@@ -884,6 +901,9 @@ CASES = {
     "rds_ei_gmm_d8_k4": lambda n: case_rds_gmm(n, d=8, K=4, B=96, N=100, seed=14),
     "rds_ddpm_gmm_d16_snr": lambda n: case_rds_gmm(n, d=16, K=4, B=64, N=32, seed=15, integrator="ddpm_like", time_type="snr"),
     "rds_em_gmm_d16": lambda n: case_rds_gmm(n, d=16, K=4, B=64, N=64, seed=16, integrator="em"),
+    # RemoveReferenceCtrl(CancelDriftCtrl) -- Langevin init on a reference solver (benchmark_utils.py:260-262), EM and EI
+    "rds_em_remove_ref_d16": lambda n: case_rds_gmm(n, d=16, K=4, B=64, N=48, seed=111, integrator="em", remove_ref=True),
+    "rds_ei_remove_ref_d40": lambda n: case_rds_gmm(n, d=40, K=3, B=48, N=32, seed=112, integrator="ei", remove_ref=True),
     "rds_em_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=64, seed=17, sde_kind="vp", integrator="em"),
     "rds_ei_vp_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=18, sde_kind="vp", integrator="ei"),
     "rds_ei_pbm_default_d16": lambda n: case_rds_default(n, d=16, K=4, B=64, N=32, seed=19, sde_kind="pbm", integrator="ei"),

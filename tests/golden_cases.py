@@ -19,7 +19,7 @@ SIM_CASES = [
     "rds_ddpm_gmm_d16_snr", "rds_em_gmm_d16", "rds_em_vp_default_d16", "rds_ei_vp_default_d16",
     "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "cmcd_phi4_d100", "pis_logreg_d61", "dds_logreg_d61", "dis_ei_d8",
     "dis_orig_lerp_d8", "rds_ei_gmm_fullcov_d128_k4", "rds_em_gmm_fullcov_d40_k3", "rds_ei_gmm_eigen_d16_k3",
-    "rds_ei_gauss_fullcov_d40", "dis_ei_cancel_drift_d8",
+    "rds_ei_gauss_fullcov_d40", "dis_ei_cancel_drift_d8", "rds_em_remove_ref_d16", "rds_ei_remove_ref_d40",
 ]
 
 
@@ -120,6 +120,10 @@ def run_oracle(c: Case, noise=None, B=None):
 
             loc0, v0 = sde.marginal_diag(torch.tensor(0.0), means, var)
             refd = orc.GMMDiag(loc0, torch.sqrt(v0), w)
+        if m.get("remove_ref"):  # RemoveReferenceCtrl(CancelDriftCtrl, ref_score, use_rescaling=False)
+            inner = orc.Ctrl(c.params("ctrl."), "cancel_drift", clip_model=m["clip_model"], target_score=tgt.score,
+                             clip_score=m["clip_score"], scale_score=m["scale_score"], sde=sde)
+            ctrl = orc.RemoveReference(inner, ref_score)
         if m["integrator"] == "em":
             out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, ref_score, noise)
         else:

@@ -44,6 +44,24 @@ def _run_full_and_shards(loss, ts, x0, args, kw):
     return full
 
 
+def _plain_equals_trajectory_twin(loss, ts, x0, args, kw, full, name, nb=8192):
+    """The benchmarked instantiation (PAR = 0: no injected-noise / trajectory paths in the step loop) against its parity-mode twin
+    (PAR = 1, selected by return_traj or noise_in -- the instantiation every injected-noise fixture test runs): same Philox normals,
+    same arithmetic, so x_N and the log-weights must agree BIT FOR BIT.  This carries the strict injected-noise evidence of
+    tests/test_gpu_parity.py over to the kernel bench.py times.  Checked on the first ``nb`` particles of the full-size batch (the
+    trajectory of all of them would be 8.6 GB at cfg 2), which by the sharding test equal rows [0, nb) of the full run."""
+    loss.particle0 = 0
+    x, rnd, xs = loss.simulate(ts, x0[:nb], *args, return_traj=True, **kw)
+    assert xs.shape == (ts.numel(), nb, x0.shape[1]) and torch.equal(xs[-1], x)
+    assert torch.equal(x, full[0][:nb]), f"{name}: PAR=1 twin x_N differs from the plain kernel's"
+    assert torch.equal(rnd, full[1][:nb]), f"{name}: PAR=1 twin log-weights differ from the plain kernel's"
+    # ... and the twin with INJECTED noise equal to the Philox stream reproduces the same bits (noise_in path = in-register path)
+    nz = E.philox_noise(int(loss.seed), ts.numel() - 1, 2048, x0.shape[1], 0, x0.device)
+    xi, rndi, _ = loss.simulate(ts, x0[:2048], *args, noise=nz, **kw)
+    assert torch.equal(xi, full[0][:2048]) and torch.equal(rndi, full[1][:2048]), f"{name}: injected Philox normals give other bits"
+    print(f"{name}: plain kernel == trajectory twin == injected-noise twin, bit for bit ({nb} / 2048 particles)")
+
+
 def _check_estimators(rnd):
     res = parallel.global_results(rnd)
     r = (-rnd.double().flatten()).cpu()
@@ -83,6 +101,7 @@ def test_cfg2_rds_gmm_65536x256(gpu):
     x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
     _check_estimators(rnd)
     _block_vs_oracle("rds_gmm", info, ts, x0, x, rnd, 5, "cfg2")
+    _plain_equals_trajectory_twin(loss, ts, x0, args, kw, (x, rnd), "cfg2")
 
 
 @pytest.mark.gpu
@@ -93,6 +112,7 @@ def test_cfg3_pis_phi4_131072x512(gpu):
     x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
     _check_estimators(rnd)
     _block_vs_oracle("pis_phi4", info, ts, x0, x, rnd, 6, "cfg3")
+    _plain_equals_trajectory_twin(loss, ts, x0, args, kw, (x, rnd), "cfg3", nb=4096)
 
 
 @pytest.mark.gpu
@@ -103,6 +123,7 @@ def test_cfg4_cmcd_logreg_shard_65536x256(gpu):
     x, rnd, _ = _run_full_and_shards(loss, ts, x0, args, kw)
     _check_estimators(rnd)
     _block_vs_oracle("cmcd_logreg", info, ts, x0, x, rnd, 7, "cfg4")
+    _plain_equals_trajectory_twin(loss, ts, x0, args, kw, (x, rnd), "cfg4")
 
 
 @pytest.mark.gpu

@@ -266,7 +266,7 @@ def test_euler_integrator_matches_reference_fixture(gpu, name):
     want = gc.run_oracle_euler(c, increment=lambda k, s, t, x: orc.philox_normal(5, k, 0, x.shape[0], x.shape[1]) * torch.sqrt(t - s))
     err_p = gc.rel_err(got.cpu(), want)
     print(f"{name}: philox mode {err_p:.2e}")
-    assert err_p < 1e-4
+    assert err_p < TOL  # achieved <= 1.2e-6 on the five fixtures
 
 
 @pytest.mark.gpu
@@ -441,4 +441,4 @@ def test_control_wrappers_with_per_step_gains_in_every_loss(gpu, wrapper, loss_k
     scale = torch.stack([ornd.flatten().abs(), tgt.logp(ox).flatten().abs(), opr.logp(ox).flatten().abs()]).max(dim=0).values.clamp(min=1.0)
     ex, er = gc.rel_err(x.cpu(), ox), float(((rnd.cpu().flatten() - ornd.flatten()).abs() / scale).max())
     print(f"{wrapper} under {loss_kind}: x_N {ex:.2e}, rnd {er:.2e}")
-    assert ex < 5 * TOL and er < 5 * TOL and float(ox.abs().max()) < 1e3
+    assert ex < TOL and er < TOL and float(ox.abs().max()) < 1e3  # achieved <= 8.4e-7 on the six combinations

@@ -1,8 +1,13 @@
 """The low-latency small-batch kernels (SDENG_FLAG_SPLIT_TILES, csrc/split_kernel.hpp): a 16-particle tile worked on by four waves.
 
-Checked against the oracle ('identical seeds': the split kernel draws the standard kernel's Philox normals) and against the standard
-kernel on the same inputs (fp32 round-off apart: the hidden-layer and per-particle sums are formed in another order), for every
-eligible feature-tile count (5..8), the three reference kinds, both forward forms, ragged and odd tile counts."""
+Held to the ORACLE ('identical seeds': the split kernel draws the standard kernel's Philox normals, which the oracle restates on the
+CPU): end points, log-weights and -- where the kernel stores them -- every state of the trajectory, for every particle of the batch
+(>= 256 wherever the case has that many), each against ITS OWN tolerance max(1e-5, 10 x that particle's sensitivity).  The
+sensitivity is measured in the oracle: the same trajectory with every normal moved by +-1.2e-6 (what separates the hardware's
+Box-Muller from libm's), three random sign patterns, per particle and per state.  Most particles do not amplify and are held to 1e-5;
+the few that sit near a separatrix between mixture components get the bound their own amplification implies, nobody gets a blanket
+allowance.  The standard kernel runs the same check on the same inputs; the two kernels' bulk agreement (median) is asserted too.
+Covered: every eligible feature-tile count (5..8), the three reference kinds, both forward forms, ragged and odd tile counts."""
 import pytest
 import torch
 
@@ -14,64 +19,119 @@ from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
 from sde_sampler_lrds_amd.losses import oc
 from sde_sampler_lrds_amd.models.reparam import ClippedCtrl
 from sde_sampler_lrds_amd.reference import MarginalReference
-from tests import golden_cases as gc
+
+TOL = 1e-5
+ORACLE_PARTICLES = 384  # particles of a batch held to the oracle (all of them when the batch is smaller)
 
 
-def _agree(std, spl, name, terms=()):
-    """Split vs standard kernel.  Both are fp32 evaluations of the same trajectory with the same normals; particles that sit near a
-    separatrix between mixture components amplify the last-bit differences of the two summation orders (each kernel is then as far
-    from the fp64 trajectory as from the other: tools/probe_split_debug.py), so the criterion is per particle: the bulk agrees to
-    round-off, at most a few per thousand may differ by more than 1e-5, none wildly.  Log-weights are judged relative to their largest
-    summand (the terminal log-densities `terms`, O(d)), like everywhere else: the two kernels evaluate a 4-mode shared-variance
-    mixture in different algebraic forms (the standard kernel's is centred, sim_device.hpp gmm_resp_centred), so their log-weights
-    differ by an ulp of that summand."""
-    ex = ((spl[0] - std[0]).abs() / std[0].abs().clamp(min=1.0)).amax(dim=1).cpu()
-    scale = max([1.0, float(std[1].abs().max())] + [float(f(std[0]).abs().max()) for f in terms])
-    er = ((spl[1] - std[1]).abs().flatten() / scale).cpu()
-    frac = float(((ex > 1e-5) | (er > 1e-5)).float().mean())
-    print(f"split vs standard {name}: x_N median {float(ex.median()):.1e} max {float(ex.max()):.1e}, rnd median {float(er.median()):.1e} max {float(er.max()):.1e}, "
-          f"particles off by > 1e-5: {100 * frac:.2f} %")
-    assert float(ex.median()) < 2e-6 and float(er.median()) < 2e-6
-    assert frac <= max(5e-3, 1.5 / ex.numel()) and float(ex.max()) < 5e-2 and bool(torch.isfinite(spl[1]).all())
+def _rel(a, b):
+    """per particle: max over features of |a - b| / max(1, |b|)"""
+    return ((a.double() - b.double()).abs() / b.double().abs().clamp(min=1.0)).amax(dim=-1)
 
 
-def _both(loss, ts, x0, args, kw):
+class OracleBlock:
+    """Oracle trajectory of particles [p0, p0 + b) with the engine's Philox stream, and each particle's own sensitivity."""
+
+    def __init__(self, run, x0, seed, p0, traj):
+        self.p0, self.b = p0, x0.shape[0]
+        base = orc.PhiloxNoise(seed, particle0=p0)
+        out = run(x0, base, traj)
+        self.x, self.rnd, self.scale, self.xs = out[0], out[1].flatten(), out[2], (out[3] if traj else None)
+        self.sx, self.sr = torch.zeros(self.b, dtype=torch.float64), torch.zeros(self.b, dtype=torch.float64)
+        self.sxs = torch.zeros(self.xs.shape[:2], dtype=torch.float64) if traj else None
+        for salt in range(3):
+            px = run(x0, bo.PerturbedNoise(base, salt=salt), traj)
+            self.sx = torch.maximum(self.sx, _rel(px[0], self.x))
+            self.sr = torch.maximum(self.sr, (px[1].flatten().double() - self.rnd.double()).abs() / self.scale)
+            if traj:
+                self.sxs = torch.maximum(self.sxs, _rel(px[3], self.xs))
+
+    def check(self, name, x, rnd, xs=None):
+        sl = slice(self.p0, self.p0 + self.b)
+        ex, er = _rel(x[sl].cpu(), self.x), (rnd[sl].cpu().flatten().double() - self.rnd.double()).abs() / self.scale
+        tx, tr = torch.clamp(10 * self.sx, min=TOL), torch.clamp(10 * self.sr, min=TOL)
+        msg = (f"{name} vs oracle, {self.b} particles: x_N max {float(ex.max()):.2e} (median {float(ex.median()):.1e}), rnd max {float(er.max()):.2e}; "
+               f"{int((tx > TOL).sum())} particles amplify beyond 1e-6 (largest own bound {float(tx.max()):.1e}); worst error / own bound "
+               f"{float((ex / tx).max()):.2f} (x_N), {float((er / tr).max()):.2f} (rnd)")
+        if xs is not None:
+            es = _rel(xs[:, sl].cpu(), self.xs)  # [N+1, b]
+            ts_ = torch.clamp(10 * self.sxs, min=TOL)
+            msg += f"; trajectory: worst state error {float(es.max()):.2e}, worst error / own bound {float((es / ts_).max()):.2f}"
+        print(msg)
+        assert bool((ex <= tx).all()) and bool((er <= tr).all()), msg
+        if xs is not None:
+            assert bool((es <= ts_).all()), msg
+
+
+def _block_of(B):
+    b = min(B, ORACLE_PARTICLES)
+    return max(0, (B - b) // 2 // 16 * 16), b
+
+
+def _both(loss, ts, x0, args, kw, **sim_kw):
     loss.split_tiles = False
-    std = loss.simulate(ts, x0, *args, **kw)
+    std = loss.simulate(ts, x0, *args, **kw, **sim_kw)
     loss.split_tiles = True
-    spl = loss.simulate(ts, x0, *args, **kw)
-    again = loss.simulate(ts, x0, *args, **kw)
+    spl = loss.simulate(ts, x0, *args, **kw, **sim_kw)
+    again = loss.simulate(ts, x0, *args, **kw, **sim_kw)
     assert torch.equal(spl[0], again[0]) and torch.equal(spl[1], again[1]), "split kernel: rerun differs"
+    if spl[2] is not None:
+        assert torch.equal(spl[2], again[2])
+    # the bulk of the particles agrees between the two kernels to fp32 round-off (same normals, sums formed in another order)
+    med = float(_rel(spl[0].cpu(), std[0].cpu()).median())
+    assert med < 2e-6 and bool(torch.isfinite(spl[1]).all()), med
     return std, spl
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("d,K,B,N", [(128, 4, 6000, 40), (128, 4, 17, 12), (100, 3, 1000, 24), (81, 2, 333, 16), (70, 4, 48, 16), (128, 1, 512, 16)])
-def test_split_kernel_mixture_reference_matches_oracle_and_standard_kernel(gpu, d, K, B, N):
+def test_split_kernel_mixture_reference_matches_oracle(gpu, d, K, B, N):
     loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=d + K)
     loss.seed = 13
     std, spl = _both(loss, ts, x0, args, kw)
-    _agree(std, spl, f"d={d} K={K} B={B}", terms=args[:2])
-    # against the oracle on a block (identical seeds), tolerance as in tests/test_gpu_fullsize.py
-    p0, pb = max(0, B // 2 - 12), min(B, 24)
+    p0, b = _block_of(B)
     run = bo.runner("rds_gmm", info, ts)
-    base = orc.PhiloxNoise(13, particle0=p0)
-    ox, ornd, sc = run(x0[p0:p0 + pb].cpu(), base)
-    sens = 0.0
-    for salt in range(2):
-        px, prnd, _ = run(x0[p0:p0 + pb].cpu(), bo.PerturbedNoise(base, salt=salt))
-        sens = max(sens, gc.rel_err(px, ox), float((prnd - ornd).abs().max()) / sc)
-    ex = gc.rel_err(spl[0][p0:p0 + pb].cpu(), ox)
-    er = float((spl[1][p0:p0 + pb].cpu().flatten() - ornd.flatten()).abs().max()) / sc
-    tol = max(1e-5, 10 * sens)
-    print(f"split vs oracle: x_N {ex:.2e}, rnd {er:.2e} (tolerance {tol:.1e})")
-    assert ex < tol and er < tol
+    blk = OracleBlock(lambda x, nz, traj: run(x, nz, return_traj=traj), x0[p0:p0 + b].cpu(), 13, p0, traj=False)
+    blk.check(f"split kernel d={d} K={K} B={B}", spl[0], spl[1])
+    blk.check(f"standard kernel d={d} K={K} B={B}", std[0], std[1])
+
+
+def _oracle_run_for(kind, cls, sde_m, target, ctrl, ref, ts):
+    """Oracle restatement of the cases of test_split_kernel_other_references_and_forms."""
+    tsc = ts.detach().cpu()
+    octrl = orc.Ctrl({k: v.detach().cpu() for k, v in ctrl.state_dict().items()}, "clipped", clip_model=1e4)
+    tgt = orc.GMMDiag(target.loc.cpu(), target.scale.cpu(), target.mixture_weights.cpu())
+    if kind == "none":
+        sde = orc.ScaledBM(float(sde_m.diff_coeff), float(sde_m.terminal_t))
+        ref_score, ref_logp = None, (lambda x: torch.zeros(x.shape[0]))
+    else:
+        sde = orc.VP(0.1, 10.0, 1.0, 1.0)
+        u = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in ref.reference_distr_utils.items()}
+        if kind == "gaussian":
+            ref_score = lambda t, x: orc.gauss_score(x, *sde.marginal_diag(t, u["x_init"], u["var_init"]))  # noqa: E731
+            loc0, v0 = sde.marginal_diag(torch.tensor(0.0), u["x_init"], u["var_init"])
+            ref_logp = orc.GaussDiag(loc0, v0.sqrt()).logp
+        else:
+            w = u["weights_init"]
+            ref_score = lambda t, x: orc.mog_score(x, w, *sde.marginal_diag(t, u["means_init"], u["variances_init"]))  # noqa: E731
+            loc0, v0 = sde.marginal_diag(torch.tensor(0.0), u["means_init"], u["variances_init"])
+            ref_logp = orc.GMMDiag(loc0, v0.sqrt(), w).logp
+
+    def run(x0, noise, traj):
+        with torch.no_grad():
+            if cls == "em":
+                x, rnd, xs = orc.simulate_em_ref(tsc, x0, octrl, sde, tgt.logp, ref_logp, ref_score, noise, return_traj=traj)
+            else:
+                x, rnd, xs = orc.simulate_ei_ref(tsc, x0, octrl, sde, tgt.logp, ref_logp, ref_score, noise, ddpm=(cls == "ddpm"), return_traj=traj)
+            return x, rnd, max(1.0, float(tgt.logp(x).abs().max()), float(rnd.abs().max())), xs
+    return run
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,cls", [("gaussian", "ei"), ("gaussian", "em"), ("none", "em"), ("gmm", "em"), ("gaussian", "ddpm")])
 def test_split_kernel_other_references_and_forms(gpu, kind, cls):
-    """Gaussian reference (RF_GAUSS), no reference (PIS-style EM with a ClippedCtrl), EM / DDPM-like forms: split vs standard kernel."""
+    """Gaussian reference (RF_GAUSS), no reference (PIS-style EM with a ClippedCtrl), a mixture with distinct variances, EM / DDPM-like
+    forms: split and standard kernel against the oracle, per particle."""
     torch.manual_seed(3)
     d, B, N = 96, 700, 20
     target = ManyModes(n_modes=3, dim=d, var=0.5, seed_loc=1, n_reference_samples=10)
@@ -95,13 +155,17 @@ def test_split_kernel_other_references_and_forms(gpu, kind, cls):
     x0 = torch.randn(B, d, device=gpu)
     refd = ref.reference_distr.to(gpu).log_prob if ref is not None else (lambda x: torch.zeros(x.shape[0], device=x.device))
     std, spl = _both(loss, ts, x0, (target.unnorm_log_prob, refd), {})
-    _agree(std, spl, f"{kind}/{cls}", terms=(target.unnorm_log_prob, refd))
+    p0, b = _block_of(B)
+    blk = OracleBlock(_oracle_run_for(kind, cls, sde, target, ctrl, ref, ts), x0[p0:p0 + b].cpu(), 5, p0, traj=False)
+    blk.check(f"split kernel {kind}/{cls}", spl[0], spl[1])
+    blk.check(f"standard kernel {kind}/{cls}", std[0], std[1])
 
 
 @pytest.mark.gpu
 def test_split_flag_is_ignored_where_no_kernel_exists(gpu):
-    """d <= 64, score controls, trajectories: the flag is a hint; the standard kernel runs and results are bit-identical."""
+    """d <= 64, score controls: the flag is a hint; the standard kernel runs and results are bit-identical."""
     from tests import build_cases as bc
+    from tests import golden_cases as gc
     for name in ("rds_ei_gmm_d8_k4", "pis_em_phi4_d100", "dds_two_modes_d2"):
         c = gc.load(name)
         b = bc.build(c, gpu)
@@ -114,27 +178,19 @@ def test_split_flag_is_ignored_where_no_kernel_exists(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("d,B,N", [(128, 512, 20), (100, 333, 12)])
-def test_split_kernel_writes_the_trajectory(gpu, d, B, N):
-    """return_traj (the first pass of compute_results, log-variance training): the split kernel stores every state; against the
-    standard kernel's trajectory, state by state."""
-    loss, ts, x0, args, kw, _ = cfgs.build_rds_gmm(gpu, B, N, d=d, K=4, seed=d)
+def test_split_kernel_trajectory_matches_oracle_state_by_state(gpu, d, B, N):
+    """return_traj (the first pass of compute_results, log-variance training): the split kernel stores every state.  EVERY stored state of
+    every particle of the block against the oracle's trajectory, each (state, particle) against its own sensitivity bound; the standard
+    kernel's trajectory (the PAR = 1 twin) passes the same check."""
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=4, seed=d)
     loss.seed = 23
-    loss.split_tiles = False
-    x_s, rnd_s, xs_s = loss.simulate(ts, x0, *args, return_traj=True)
-    loss.split_tiles = True
-    x, rnd, xs = loss.simulate(ts, x0, *args, return_traj=True)
+    std, spl = _both(loss, ts, x0, args, kw, return_traj=True)
+    x, rnd, xs = spl
     assert xs.shape == (N + 1, B, d) and torch.equal(xs[0], x0) and torch.equal(xs[-1], x)
-    again = loss.simulate(ts, x0, *args, return_traj=True)
-    assert torch.equal(again[2], xs) and torch.equal(again[1], rnd)
     plain = loss.simulate(ts, x0, *args)  # the same launch without the stores
     assert torch.equal(plain[0], x) and torch.equal(plain[1], rnd)
-    _agree((x_s, rnd_s), (x, rnd), f"trajectory d={d}", terms=args[:2])
-    # state by state, per particle (a particle near a separatrix amplifies the last-bit differences mid-way and contracts again later:
-    # the criterion of _agree, applied to every step)
-    err = ((xs - xs_s).abs() / xs_s.abs().clamp(min=1.0)).amax(dim=2).cpu()  # [N+1, B]
-    med, frac = err.median(dim=1).values, (err > 1e-5).float().mean(dim=1)
-    print(f"split vs standard trajectory d={d}: per-step median particle error <= {float(med.max()):.1e}, particles off by > 1e-5 <= {100 * float(frac.max()):.2f} %, "
-          f"worst {float(err.max()):.1e}")
-    # (the first coarse steps are the sensitive ones -- particles start between the modes, where the responsibilities react to the
-    # last bits of logits of size ~1e3; measured: up to 5 % of the particles beyond 1e-5 at step 3 of 12, 0.3 % at the end)
-    assert float(med.max()) < 2e-6 and float(frac.max()) <= 0.10 and float(frac[-1]) <= 0.01 and float(err.max()) < 5e-2
+    p0, b = _block_of(B)
+    run = bo.runner("rds_gmm", info, ts)
+    blk = OracleBlock(lambda xx, nz, traj: run(xx, nz, return_traj=traj), x0[p0:p0 + b].cpu(), 23, p0, traj=True)
+    blk.check(f"split kernel trajectory d={d}", x, rnd, xs)
+    blk.check(f"standard kernel trajectory d={d}", std[0], std[1], std[2])

@@ -26,7 +26,9 @@ def test_lv_training_loss_and_gradients_match_reference(gpu, name):
     kw = {k: v for k, v in b["kwargs"].items() if k == "initial_log_prob"}
     value, metrics = loss(b["ts"], b["x0"], *b["args"], **kw)
     value.backward()
-    assert abs(float(value.detach()) - c.meta["loss"]) < 2e-4 * max(1.0, abs(c.meta["loss"])), (float(value.detach()), c.meta["loss"])
+    # tolerances = 10 x the worst achieved over the seven fixtures on MI355X (loss value 1.2e-6 relative, gradients 5.0e-6 of the largest entry)
+    loss_err = abs(float(value.detach()) - c.meta["loss"]) / max(1.0, abs(c.meta["loss"]))
+    assert loss_err < 1e-5, (float(value.detach()), c.meta["loss"])
     worst = 0.0
     for k, p in ctrl.named_parameters():
         if "grad." + k not in c.a:
@@ -34,8 +36,8 @@ def test_lv_training_loss_and_gradients_match_reference(gpu, name):
         ref = c["grad." + k]
         err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
         worst = max(worst, err)
-        assert err < 2e-3, (k, err)
-    print(f"{name}: loss {float(value.detach()):.6f} vs {c.meta['loss']:.6f}; worst relative gradient error {worst:.2e}")
+        assert err < 5e-5, (k, err)
+    print(f"{name}: loss {float(value.detach()):.6f} vs {c.meta['loss']:.6f} (rel {loss_err:.1e}); worst relative gradient error {worst:.2e}")
     assert "train/n_filtered_cumulative" in metrics
 
 

@@ -38,7 +38,10 @@ def test_make_model_rds_gmm_evaluate(gpu):
     ("dis_orig", "default", "em", "target_informed_lerp_tempering", "uniform", "many_modes", dict(sigma=1.0)),
     ("vp-ref", "default", "ddpm_like", "base_zero_init", "snr", "many_modes", dict(sigma=1.0)),
     ("pbm-ref", "default", "ei", "base_zero_init", "snr", "many_modes", dict(sigma=0.4472135954999579)),
-    ("pis_orig", "default", "em", "target_informed_langevin_init", "uniform", "bracket_two_modes", dict(sigma=0.4472135954999579)),
+    # Langevin init on a reference solver (benchmark_utils.py:260-262): the loss keeps the CancelDriftCtrl, the solver's attribute is wrapped
+    ("vp-ref", "gmm", "em", "target_informed_langevin_init", "uniform", "bracket_two_modes",
+     dict(means_ref=torch.tensor([[1.0] * 8, [-1.0] * 8]), variances_ref=0.5 * torch.ones(2, 8), weights_ref=torch.ones(2))),
+    ("vp-ref", "default", "em", "target_informed_langevin_init", "snr", "many_modes", dict(sigma=1.0)),
     ("dis_orig", "default", "em", "target_informed_langevin_init", "uniform", "many_modes", dict(sigma=1.0)),
     ("vp-ref", "default", "ei", "base_zero_init", "uniform", "two_modes_full", dict(sigma=1.0)),  # full-covariance target: terminal cost via torch
     ("cmcd", "default", "em", "target_informed_zero_init", "uniform", "many_modes", dict()),
@@ -50,6 +53,16 @@ def test_make_model_variants_run(gpu, solver, ref, integ, mtype, time_type, tnam
     res = model.evaluate()
     assert torch.isfinite(res.samples).all() and torch.isfinite(res.weights).all()
     assert res.samples.shape[0] == 512
+    if mtype == "target_informed_langevin_init" and "ref" in solver:
+        assert type(model.generative_ctrl).__name__ == "RemoveReferenceCtrl" and model.loss.generative_ctrl is model.generative_ctrl.score
+
+
+@pytest.mark.gpu
+def test_make_model_rejects_what_the_reference_rejects(gpu):
+    """(the full accept / reject table is tests/test_make_model_contract.py, on the CPU)"""
+    tgt = make_target_details("bracket_two_modes", dim=8)
+    with pytest.raises(ValueError, match="Only target_informed_zero_init model is supported."):
+        make_model("pis_orig", "default", "lv", "em", "target_informed_langevin_init", "uniform", dict(sigma=0.4472135954999579), tgt, _train(512))
 
 
 @pytest.mark.gpu

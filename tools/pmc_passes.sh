@@ -12,6 +12,7 @@ export PROBE_REPS=2 PROBE_CFG=$CFG
 i=0
 for SET in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
+  "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INST_CYCLES_SALU SQ_IFETCH SQ_BUSY_CU_CYCLES" \
   "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" \
   "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT64" \
   "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
@@ -25,8 +26,10 @@ PROBE_REPS=6 timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format 
 echo "kernel-trace rc=$?" >> $OUT/summary.txt
 cp $(ls $OUT/kt/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/kernel_stats.csv 2>/dev/null
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, sys
 out, cfg = "$OUT", "$CFG"
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+from sde_sampler_lrds_amd import build as _build
 acc = collections.defaultdict(list)
 kname = None
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
@@ -53,5 +56,5 @@ try:
             kt = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
 except Exception as e:
     print("no kernel stats:", e)
-json.dump({"workload": cfg, "kernel": kname, "counters_per_launch": res, "traffic": traffic, "kernel_trace": kt}, open(out + "/counters.json", "w"), indent=1)
+json.dump({"workload": cfg, "kernel": kname, "library_digest": _build._digest(), "counters_per_launch": res, "traffic": traffic, "kernel_trace": kt}, open(out + "/counters.json", "w"), indent=1)
 PY
