@@ -27,7 +27,7 @@ enum { CT_LOGREG = 0, CT_GMM = 1, CT_PHI4 = 2 };  // target kind is a template p
 // needs drift(t, y) for the cost and drift(s, y) for the next move: same scores, two mixes)
 template <int NT, int TGT, bool TWO = false>
 SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float w_t, float w_1mt, const float* lds,
-                         const float* bias, int lane, f32x4 (&u)[NT], f32x4 (&b)[NT], f32x4 (&b2)[NT], float w2_t = 0.0f,
+                         const float* bias, const NetScale& ns, int lane, f32x4 (&u)[NT], f32x4 (&b)[NT], f32x4 (&b2)[NT], float w2_t = 0.0f,
                          float w2_1mt = 0.0f) {
   constexpr int KB = (NT + 1) / 2;
   const int g = lane >> 4;
@@ -121,14 +121,14 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
 
   // ---- control ----
   f32x4 hid[SD_HT];
-  mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane);
+  mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane, ns);
   __builtin_amdgcn_s_setprio(1);  // end of the matrix phase (raised at the top of this function); the rest of the step runs at 1
   const HidSplit hs = split_hidden(hid);
   const float st = s.stheta ? s.stheta[ki] : 1.0f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     f32x4 o[1];
-    mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, o);
+    mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, o, ns.inv_out);
     if constexpr (NT <= 4) {
       if (s.clip_model > 0.0f) clamp_tile_rare(o[0], s.clip_model);
       if (s.ctrl_kind == SDENG_CTRL_SCORE) {
@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
   }
   __syncthreads();
   const float* bias = s.wpack + sd_off_bias(NT);
+  const NetScale ns = load_net_scale(bias, NT);
   const int p = lane & 15, g = lane >> 4;
   float* trash = s.trash + tid * 4;
   const float gg = s.cmcd_g, inv_g = 1.0f / s.cmcd_g;
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     f32x4 w_s[NT];
     if (s.N > 0) {
       f32x4 u0[NT], b0[NT];
-      cmcd_eval<NT, TGT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, lane, u0, b0, b0);
+      cmcd_eval<NT, TGT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, ns, lane, u0, b0, b0);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -238,9 +239,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
         f32x4 u_t[NT], b_t[NT], b_n[EUBO ? NT : 1];
         if constexpr (EUBO) {  // weights of t (cols 6,7 of the row) for the cost, of s (cols 4,5 of the NEXT row) for the next move
           const float* cn = cf + SDENG_NCOEF;
-          cmcd_eval<NT, TGT, true>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t, b_n, cn[4], cn[5]);
+          cmcd_eval<NT, TGT, true>(a, x, k + 1, cf[6], cf[7], lds, bias, ns, lane, u_t, b_t, b_n, cn[4], cn[5]);
         } else {
-          cmcd_eval<NT, TGT>(a, x, k + 1, cf[6], cf[7], lds, bias, lane, u_t, b_t, b_t);
+          cmcd_eval<NT, TGT>(a, x, k + 1, cf[6], cf[7], lds, bias, ns, lane, u_t, b_t, b_t);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)

@@ -15,8 +15,43 @@
 // ------------------------------------------------------------------------------------------------
 // One thread per 16-bit half of the image.  Block (to, kb), part (0 = hi, 1 = lo), lane, j:
 //   w = W[16 to + (lane & 15)][16 (2 kb + j/4) + 4 (lane >> 4) + j%4];  hi = f16(w);  lo = f16((w - hi) * 2^11)
+// Per-matrix power-of-two scale (sim_common.hpp SD_N_SCALES): one block, the four matrices one after the other.
+__global__ void __launch_bounds__(256) k_weight_scales(PackArgs a) {
+  __shared__ float red[256];
+  float* sc = a.out + sd_off_scales(a.NT);
+  for (int l = 0; l < 4; ++l) {
+    const float* W = l == 0 ? a.w_in : (l == 1 ? a.w_h1 : (l == 2 ? a.w_h2 : a.w_out));
+    const int n = (l == 0 || l == 3) ? SD_H * a.d : SD_H * SD_H;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float v = __builtin_fabsf(W[i]);
+      m = (v <= 3.0e38f) ? fmaxf(m, v) : m;  // non-finite weights do not decide the scale (they poison the result either way)
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float mx = red[0];
+      int e = 0;
+      if (mx > 0.0f && (mx < 9.765625e-4f || mx >= 16384.0f)) {  // outside [2^-10, 2^14): normalise the largest entry to [1, 2)
+        int ex;
+        frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
+        e = 1 - ex;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      }
+      sc[l] = ldexpf(1.0f, e);
+      sc[4 + l] = ldexpf(1.0f, -e);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void k_pack_mlp(PackArgs a) {
   const int NT = a.NT;
+  const float* scales = a.out + sd_off_scales(NT);  // written by k_weight_scales, launched ahead of this kernel
   const int n_half = sd_lds_weight_floats(NT) * 2;
   const int n_bias = 3 * 64 + 16 * NT;
   _Float16* img = reinterpret_cast<_Float16*>(a.out);
@@ -24,15 +59,15 @@ __global__ void k_pack_mlp(PackArgs a) {
     if (idx < n_half) {
       const int fl = idx >> 1;  // float-equivalent offset, to find the layer
       const float* W;
-      int n_out, n_in, KB, base;
+      int n_out, n_in, KB, base, layer;
       if (fl < sd_off_wh1(NT)) {
-        W = a.w_in; n_out = SD_H; n_in = a.d; KB = sd_kb(NT); base = sd_off_win(NT);
+        W = a.w_in; n_out = SD_H; n_in = a.d; KB = sd_kb(NT); base = sd_off_win(NT); layer = 0;
       } else if (fl < sd_off_wh2(NT)) {
-        W = a.w_h1; n_out = SD_H; n_in = SD_H; KB = 2; base = sd_off_wh1(NT);
+        W = a.w_h1; n_out = SD_H; n_in = SD_H; KB = 2; base = sd_off_wh1(NT); layer = 1;
       } else if (fl < sd_off_wout(NT)) {
-        W = a.w_h2; n_out = SD_H; n_in = SD_H; KB = 2; base = sd_off_wh2(NT);
+        W = a.w_h2; n_out = SD_H; n_in = SD_H; KB = 2; base = sd_off_wh2(NT); layer = 2;
       } else {
-        W = a.w_out; n_out = a.d; n_in = SD_H; KB = 2; base = sd_off_wout(NT);
+        W = a.w_out; n_out = a.d; n_in = SD_H; KB = 2; base = sd_off_wout(NT); layer = 3;
       }
       const int local = idx - 2 * base;          // half index inside the layer
       const int j = local & 7;
@@ -42,16 +77,17 @@ __global__ void k_pack_mlp(PackArgs a) {
       const int kb = blk % KB, to = blk / KB;
       const int o = 16 * to + (lane & 15);
       const int i = 16 * (2 * kb + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
-      const float w = (o < n_out && i < n_in) ? W[static_cast<size_t>(o) * n_in + i] : 0.0f;
+      const float w = (o < n_out && i < n_in) ? W[static_cast<size_t>(o) * n_in + i] * scales[layer] : 0.0f;  // power of two: exact
       const _Float16 hi = static_cast<_Float16>(w);
       img[idx] = part == 0 ? hi : static_cast<_Float16>((w - static_cast<float>(hi)) * 2048.0f);
     } else {
       const int b = idx - n_half;
       float v;
-      if (b < 64) v = a.b_in[b];
-      else if (b < 128) v = a.b_h1[b - 64];
-      else if (b < 192) v = a.b_h2[b - 128];
-      else v = (b - 192 < a.d) ? a.b_out[b - 192] : 0.0f;
+      // biases carry their layer's scale too: they are the initial value of the layer's accumulator
+      if (b < 64) v = a.b_in[b] * scales[0];
+      else if (b < 128) v = a.b_h1[b - 64] * scales[1];
+      else if (b < 192) v = a.b_h2[b - 128] * scales[2];
+      else v = (b - 192 < a.d) ? a.b_out[b - 192] * scales[3] : 0.0f;
       a.out[sd_off_bias(NT) + b] = v;
     }
   }
@@ -877,6 +913,7 @@ int sd_launch_sample_x0(const sdeng_dist& ds, unsigned lo, unsigned hi, long lon
 // ---- host-side launch wrappers -------------------------------------------------------------------
 int sd_launch_pack(const PackArgs& a, hipStream_t s) {
   const int total = sd_lds_weight_floats(a.NT) * 2 + 3 * 64 + 16 * a.NT;
+  hipLaunchKernelGGL(k_weight_scales, dim3(1), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_pack_mlp, dim3((total + 255) / 256), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }

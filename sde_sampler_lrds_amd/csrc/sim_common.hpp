@@ -45,7 +45,14 @@ __host__ __device__ inline int sd_off_wh2(int NT) { return sd_off_wh1(NT) + 4 * 
 __host__ __device__ inline int sd_off_wout(int NT) { return sd_off_wh2(NT) + 4 * 2 * 512; }
 __host__ __device__ inline int sd_lds_weight_floats(int NT) { return sd_off_wout(NT) + NT * 2 * 512; }
 __host__ __device__ inline int sd_off_bias(int NT) { return sd_lds_weight_floats(NT); }
-__host__ __device__ inline int sd_pack_floats(int NT) { return sd_lds_weight_floats(NT) + 3 * 64 + 16 * NT; }
+// Power-of-two prescale of the four weight matrices (k_weight_scales, prep_kernels.hip): the f16 split v = hi + lo 2^-11 carries fp32's
+// 22+ bits only while |v| sits in f16's NORMAL range, so a matrix whose largest entry is below 2^-10 (the reference initialises the last
+// layer at ~1e-7, models/utils.py:7-22: f16-subnormal) or at / above 2^14 is stored as W * 2^e with max |W| 2^e in [1, 2), its bias as
+// b * 2^e, and the layer's output is multiplied by 2^-e (exact).  Matrices already in range keep e = 0 and the old bits.
+// Behind the biases: scale[4] = 2^e per layer (in, h1, h2, out), then inv[4] = 2^-e.
+#define SD_N_SCALES 8
+__host__ __device__ inline int sd_off_scales(int NT) { return sd_off_bias(NT) + 3 * 64 + 16 * NT; }
+__host__ __device__ inline int sd_pack_floats(int NT) { return sd_off_scales(NT) + SD_N_SCALES; }
 // per-wave LDS copy of one step's reference table [K][2][dpad]; used while K*2*dpad <= SD_REFTAB_FLOATS
 #define SD_REFTAB_FLOATS 1024
 // workgroup-shared copy of a larger mixture's table (RF_GMM_BIG): `share` chunks of 1 KiB per wave, two buffers

@@ -124,8 +124,10 @@ SD_INLINE void split8_half(const f32x4& t0, f16x8& hi, f16x8& lo) {
 
 // one layer: out[to] = bias[to] (preloaded in `out`) + W in.  The activations are split K-block by K-block right
 // before use, so only 8 packed registers of hi/lo pieces are live at a time.
-template <int NTI, int TO>
-SD_INLINE void dense(const f32x4 (&in)[NTI], f32x4 (&out)[TO], const float* w, int lane) {
+// SCALED: the B operand is in * sg (sg per lane, i.e. per particle: the range-safe twin below), formed K-block by K-block so that no
+// scaled copy of the whole input is ever live
+template <int NTI, int TO, bool SCALED = false>
+SD_INLINE void dense(const f32x4 (&in)[NTI], f32x4 (&out)[TO], const float* w, int lane, float sg = 1.0f) {
   constexpr int KB = (NTI + 1) / 2;
   const f16x8* w8 = reinterpret_cast<const f16x8*>(w);
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -135,8 +137,13 @@ SD_INLINE void dense(const f32x4 (&in)[NTI], f32x4 (&out)[TO], const float* w, i
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     f16x8 xh, xl;
-    if (2 * kb + 1 < NTI) split8(in[2 * kb], in[2 * kb + 1 < NTI ? 2 * kb + 1 : 0], xh, xl);
-    else split8_half(in[2 * kb], xh, xl);
+    if constexpr (SCALED) {
+      if (2 * kb + 1 < NTI) split8(in[2 * kb] * sg, in[2 * kb + 1 < NTI ? 2 * kb + 1 : 0] * sg, xh, xl);
+      else split8_half(in[2 * kb] * sg, xh, xl);
+    } else {
+      if (2 * kb + 1 < NTI) split8(in[2 * kb], in[2 * kb + 1 < NTI ? 2 * kb + 1 : 0], xh, xl);
+      else split8_half(in[2 * kb], xh, xl);
+    }
     f16x8 ah[TO], al[TO];
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
@@ -227,6 +234,24 @@ SD_INLINE void gelu_tiles(f32x4 (&v)[T]) {
     for (int r = 0; r < 4; ++r) v[t][r] = gelu_fast(v[t][r]);
 }
 
+// Layer scales of the packed drift net (sim_common.hpp SD_N_SCALES): inv_* = 2^-e of each layer, s_in = 2^e of the input layer.
+// All 1.0 for a net whose weights sit in the f16 split's good range -- then nothing below changes a bit of the result.
+struct NetScale {
+  float inv_in, inv_h1, inv_h2, inv_out, s_in;
+};
+SD_INLINE NetScale load_net_scale(const float* bias, int NT) {
+  const float* sc = bias + 3 * 64 + 16 * NT;  // uniform address: scalar loads, loop invariant
+  return NetScale{sc[4], sc[5], sc[6], sc[7], sc[0]};
+}
+// layer output *= 2^-e, behind ONE uniform test per layer (a multiply per element would cost the common case ~2 % for nothing)
+template <int T>
+SD_INLINE void unscale_tiles(f32x4 (&v)[T], float inv) {
+  if (inv != 1.0f) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) v[t] = v[t] * inv;
+  }
+}
+
 // FourierMLP.forward (models/mlp.py:135-143) for a 16-particle tile, split in two so that the d-wide output
 // never has to be live at once: mlp_hidden() runs input_embed + time embedding + the two hidden layers and
 // returns gelu(h) (64 channels = 4 register tiles); mlp_out_tiles() produces OT 16-feature tiles of out_layer,
@@ -234,46 +259,110 @@ SD_INLINE void gelu_tiles(f32x4 (&v)[T]) {
 // embedding [64] (hoisted: the reference recomputes the identical row for every particle, :136-137).
 template <int NT>
 SD_INLINE void mlp_hidden(const f32x4 (&x)[NT], f32x4 (&a)[SD_HT], const float* lds, const float* bias, const float* temb,
-                          int lane) {
+                          int lane, const NetScale& ns) {
   const int g = lane >> 4;
   f32x4 b[SD_HT];
 #pragma unroll
-  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias, t, g);  // b_in
+  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias, t, g);  // b_in (times the layer's scale, like the weights)
   dense<NT, SD_HT>(x, a, lds + sd_off_win(NT), lane);
 #pragma unroll
-  for (int t = 0; t < SD_HT; ++t) a[t] = a[t] + load_tile4(temb, t, g);  // embed = embed_x + embed_t
+  for (int t = 0; t < SD_HT; ++t) {  // embed = embed_x + embed_t; the input layer's 2^-e rides on the add (fma(v, 1, t) = v + t bit for bit)
+    const f32x4 te = load_tile4(temb, t, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[t][r] = __builtin_fmaf(a[t][r], ns.inv_in, te[r]);
+  }
   gelu_tiles<SD_HT>(a);
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) b[t] = load_tile4(bias + 64, t, g);  // b_h1
   dense<SD_HT, SD_HT>(a, b, lds + sd_off_wh1(NT), lane);
+  unscale_tiles<SD_HT>(b, ns.inv_h1);
   gelu_tiles<SD_HT>(b);
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias + 128, t, g);  // b_h2
   dense<SD_HT, SD_HT>(b, a, lds + sd_off_wh2(NT), lane);
+  unscale_tiles<SD_HT>(a, ns.inv_h2);
+  gelu_tiles<SD_HT>(a);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Range-safe twin of the drift net.  The split operands are f16: a state or an activation beyond 65 504 becomes inf there and the
+// step would return NaN where the reference (fp32 GEMMs) stays finite.  The step loop detects that after the fact -- one compare per
+// tile-step on an output every input of the particle feeds, sim_kernel.hpp -- and re-evaluates the net of that step here: every
+// layer's B operand is the input times a per-PARTICLE power of two sigma that brings the row's largest entry below 2^10, the
+// accumulator starts at zero and the output is (acc / sigma + bias) 2^-e.  Exact scalings; never taken by a healthy sampler.
+// ----------------------------------------------------------------------------------------------
+template <int T>
+SD_INLINE float row_downscale(const f32x4 (&v)[T]) {
+  float m = 0.0f;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fabsf(v[t][r]));  // (fmaxf drops NaNs: they poison the row by themselves)
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (!(m >= 1024.0f) || !(m <= 3.0e38f)) return 1.0f;
+  int ex;
+  frexpf(m, &ex);  // m = f 2^ex, f in [0.5, 1)
+  return ldexpf(1.0f, 10 - ex);
+}
+template <int NTI, int TO>
+SD_INLINE void dense_safe(const f32x4 (&in)[NTI], f32x4 (&out)[TO], const float* w, const float* bias_scaled, float inv, int lane) {
+  const int g = lane >> 4;
+  constexpr int KB = (NTI + 1) / 2;
+  const float sg = row_downscale<NTI>(in), rs = 1.0f / sg;  // powers of two: exact
+  // one output tile at a time (the input is split again for each): this path is cold, what matters is that it adds no register pressure
+  // to the step loop it sits in (the three-waves-per-SIMD instantiations have 168 registers)
+#pragma unroll
+  for (int to = 0; to < TO; ++to) {
+    f32x4 o1[1] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+    dense<NTI, 1, true>(in, o1, w + to * KB * 512, lane, sg);
+    const f32x4 b = load_tile4(bias_scaled, to, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[to][r] = __builtin_fmaf(o1[0][r], rs, b[r]) * inv;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int NT>
+SD_INLINE void mlp_hidden_safe(const f32x4 (&x)[NT], f32x4 (&a)[SD_HT], const float* lds, const float* bias, const float* temb,
+                               int lane, const NetScale& ns) {
+  const int g = lane >> 4;
+  f32x4 b[SD_HT];
+  dense_safe<NT, SD_HT>(x, a, lds + sd_off_win(NT), bias, ns.inv_in, lane);
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) a[t] = a[t] + load_tile4(temb, t, g);
+  gelu_tiles<SD_HT>(a);
+  dense_safe<SD_HT, SD_HT>(a, b, lds + sd_off_wh1(NT), bias + 64, ns.inv_h1, lane);
+  gelu_tiles<SD_HT>(b);
+  dense_safe<SD_HT, SD_HT>(b, a, lds + sd_off_wh2(NT), bias + 128, ns.inv_h2, lane);
   gelu_tiles<SD_HT>(a);
 }
 
 // mlp_hidden with the input layer fed from a pre-split state
 template <int NT>
 SD_INLINE void mlp_hidden_pre(const f16x8 (&xh)[(NT + 1) / 2], const f16x8 (&xl)[(NT + 1) / 2], f32x4 (&a)[SD_HT], const float* lds,
-                              const float* bias, const float* temb, int lane) {
+                              const float* bias, const float* temb, int lane, const NetScale& ns) {
   const int g = lane >> 4;
   f32x4 b[SD_HT], mx[SD_HT];
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) {
-    a[t] = load_tile4(bias, t, g) + load_tile4(temb, t, g);  // b_in + embed_t
+    const f32x4 bi = load_tile4(bias, t, g), te = load_tile4(temb, t, g);  // b_in 2^e + embed_t 2^e (fma(t, 1, b) = t + b bit for bit)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[t][r] = __builtin_fmaf(te[r], ns.s_in, bi[r]);
     mx[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
   dense_pre<(NT + 1) / 2, SD_HT>(xh, xl, a, mx, reinterpret_cast<const f16x8*>(lds + sd_off_win(NT)), lane);
   fold_lo<SD_HT>(a, mx);
+  unscale_tiles<SD_HT>(a, ns.inv_in);
   gelu_tiles<SD_HT>(a);
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) b[t] = load_tile4(bias + 64, t, g);  // b_h1
   dense<SD_HT, SD_HT>(a, b, lds + sd_off_wh1(NT), lane);
+  unscale_tiles<SD_HT>(b, ns.inv_h1);
   gelu_tiles<SD_HT>(b);
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias + 128, t, g);  // b_h2
   dense<SD_HT, SD_HT>(b, a, lds + sd_off_wh2(NT), lane);
+  unscale_tiles<SD_HT>(a, ns.inv_h2);
   gelu_tiles<SD_HT>(a);
 }
 
@@ -287,16 +376,43 @@ SD_INLINE HidSplit split_hidden(const f32x4 (&a)[SD_HT]) {
   return s;
 }
 template <int NT, int OT>
-SD_INLINE void mlp_out_tiles(const HidSplit& hs, const float* lds, const float* bias, int t0, int lane, f32x4 (&u)[OT]) {
+SD_INLINE void mlp_out_tiles(const HidSplit& hs, const float* lds, const float* bias, int t0, int lane, f32x4 (&u)[OT], float inv_out) {
   const int g = lane >> 4;
   f32x4 mx[OT];
 #pragma unroll
   for (int o = 0; o < OT; ++o) {
-    u[o] = load_tile4(bias + 192, t0 + o, g);  // b_out
+    u[o] = load_tile4(bias + 192, t0 + o, g);  // b_out (times the layer's scale)
     mx[o] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
   dense_pre<2, OT>(hs.h, hs.l, u, mx, reinterpret_cast<const f16x8*>(lds + sd_off_wout(NT) + t0 * 2 * 512), lane);
   fold_lo<OT>(u, mx);
+  unscale_tiles<OT>(u, inv_out);
+}
+// range-safe twin (mlp_hidden_safe): `hs` is the split of hid * sigma, `rs` = 1 / sigma of this lane's particle
+template <int NT, int OT>
+SD_INLINE void mlp_out_tiles_safe(const HidSplit& hs, float rs, const float* lds, const float* bias, int t0, int lane, f32x4 (&u)[OT],
+                                  float inv_out) {
+  const int g = lane >> 4;
+  f32x4 mx[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) u[o] = mx[o] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  dense_pre<2, OT>(hs.h, hs.l, u, mx, reinterpret_cast<const f16x8*>(lds + sd_off_wout(NT) + t0 * 2 * 512), lane);
+  fold_lo<OT>(u, mx);
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+    const f32x4 b = load_tile4(bias + 192, t0 + o, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[o][r] = __builtin_fmaf(u[o][r], rs, b[r]) * inv_out;
+  }
+}
+// the last hidden activation of the safe path, split with its per-particle factor; returns 1 / sigma
+SD_INLINE float split_hidden_safe(const f32x4 (&a)[SD_HT], HidSplit& s) {
+  const float sg = row_downscale<SD_HT>(a);
+  f32x4 sc[SD_HT];
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) sc[t] = a[t] * sg;
+  split_tiles<SD_HT>(sc, s.h, s.l);
+  return 1.0f / sg;
 }
 
 // ----------------------------------------------------------------------------------------------

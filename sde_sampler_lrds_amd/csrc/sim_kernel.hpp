@@ -125,6 +125,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
 #endif
   static_assert(SC != SC_LOGREG || (REF == RF_NONE && NT <= 4), "in-loop logistic-regression score: no reference, d <= 64");
   const float* bias = a.wpack + sd_off_bias(NT);
+  const NetScale ns = load_net_scale(bias, NT);
   // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)
 #ifdef SD_DBG_NODMA
   constexpr bool ref_lds = false;
@@ -228,9 +229,12 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       // -- hidden layers 2, the whole tail (output layer, noise, integrator) 1, scores and bookkeeping 0 -- are worth another 2.4 %
       // (4.74 -> 4.63, 15.22 -> 14.86): profiles/r02_issue_priority.log.
       __builtin_amdgcn_s_setprio(2);
-      mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
+      mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane, ns);
       __builtin_amdgcn_s_setprio(1);
-      const HidSplit hs = split_hidden(hid);
+      HidSplit hs = split_hidden(hid);
+      // range guard (sim_device.hpp mlp_hidden_safe): set by the first output tile of the step when an f16 operand overflowed
+      bool safe_net = false;
+      float hid_rs = 1.0f;
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
       f32x4 ts[SC != SC_NONE ? NT : 1];
@@ -468,7 +472,26 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       auto out_group = [&](auto otc, int t0) __attribute__((always_inline)) {
         constexpr int OT = decltype(otc)::value;
         f32x4 u[OT];
-        mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
+        if (__builtin_expect(safe_net, 0)) mlp_out_tiles_safe<NT, OT>(hs, hid_rs, lds, bias, t0, lane, u, ns.inv_out);
+        else mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u, ns.inv_out);
+        // (not in the kernels whose reference / target score puts the state itself through split-f16 products -- matrix-pipe and
+        // full-covariance mixtures, the in-loop logistic-regression score: those products have no twin, the guard would be half a guard)
+        constexpr bool range_guard = REF != RF_GMM_MM && REF != RF_GMM_FULL && SC != SC_LOGREG;
+        if (range_guard && t0 == 0) {
+          // A state or an activation beyond f16's range (65 504) turned into inf in a split operand: every output of that particle is
+          // then inf or NaN, so ONE compare on the first output register finds it.  The net of this step is evaluated again through
+          // the range-safe twin (per-particle power-of-two scaling of every layer's input) -- x has not been touched yet.  The
+          // reference's fp32 GEMMs stay finite there, and so does this; inputs that are non-finite themselves stay non-finite.
+          const bool bad = !(__builtin_fabsf(u[0][0]) <= 3.0e38f);
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+            asm volatile("" ::: "memory");  // nothing of the cold path is to be prepared ahead of this test
+            safe_net = true;
+            mlp_hidden_safe<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane, ns);
+            hid_rs = split_hidden_safe(hid, hs);
+            mlp_out_tiles_safe<NT, OT>(hs, hid_rs, lds, bias, t0, lane, u, ns.inv_out);
+            asm volatile("" ::: "memory");
+          }
+        }
         if (a.clip_model > 0.0f) {
           // ClippedCtrl's clip (reparam.py:42) almost never binds (clip_model = 1e4): one compare per element into a
           // wave-wide mask, and the 4-instruction NaN-preserving clamp only when some lane is out of range or NaN
@@ -583,6 +606,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
   }
   __syncthreads();
   const float* bias = a.wpack + sd_off_bias(NT);
+  const NetScale ns = load_net_scale(bias, NT);
   const int p = lane & 15, g = lane >> 4;
   float* trash = a.trash + tid * 4;
   for (int tile = blockIdx.x + gridDim.x * wave; tile < a.ntiles; tile += gridDim.x * SD_WAVES) {  // CUs first
@@ -592,8 +616,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
     load_rows<NT>(a.x_in, row, a.d, live, g, x);
     const float score_gain = a.coef[7], lerp_w = a.coef[8];
     f32x4 hid[SD_HT];
-    mlp_hidden<NT>(x, hid, lds, bias, a.temb, lane);
-    const HidSplit hs = split_hidden(hid);
+    mlp_hidden<NT>(x, hid, lds, bias, a.temb, lane, ns);
+    HidSplit hs = split_hidden(hid);
+    bool safe_net = false;  // range guard, as in the step loop
+    float hid_rs = 1.0f;
     f32x4 ts[SC != SC_NONE ? NT : 1];
     if constexpr (SC == SC_GMM) {
       if (NT == 1 && a.target.kind == SDENG_DIST_RINGS) ts[0] = rings_score(x[0], a.target, g);
@@ -606,7 +632,17 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4 u[1];
-      mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, u);
+      if (safe_net) mlp_out_tiles_safe<NT, 1>(hs, hid_rs, lds, bias, t, lane, u, ns.inv_out);
+      else mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, u, ns.inv_out);
+      if (t == 0) {
+        const bool bad = !(__builtin_fabsf(u[0][0]) <= 3.0e38f);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+          safe_net = true;
+          mlp_hidden_safe<NT>(x, hid, lds, bias, a.temb, lane, ns);
+          hid_rs = split_hidden_safe(hid, hs);
+          mlp_out_tiles_safe<NT, 1>(hs, hid_rs, lds, bias, t, lane, u, ns.inv_out);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (a.clip_model > 0.0f) u[0][r] = clampf(u[0][r], a.clip_model);

@@ -20,8 +20,11 @@
 // A workgroup = 8 waves = two tiles side by side (the LDS weight image allows one workgroup per CU), so every SIMD interleaves two
 // waves.  Per wave and step: ~36 MFMAs and ~800 vector instructions instead of 144 and 2 660.  Noise counters are those of the
 // standard kernel (same normals); the hidden-layer sums and the per-particle reductions are formed in a different order, so results
-// agree with the standard kernel to fp32 round-off, not bit for bit -- which is why the path is opt-in (sdeng.h).
-// Scope: ClippedCtrl, forward forms (LIN / EM), no / Gaussian / small-mixture (K <= 4) reference, d > 64, no trajectory or injected noise.
+// agree with the standard kernel to fp32 round-off, not bit for bit -- which is why the path is a flag of the ABI (sdeng.h); the Python
+// solvers set it by default for evaluation / training batches of at most 8 192 particles (solver cfg 'split_tiles').
+// Scope: ClippedCtrl, forward forms (LIN / EM), no / Gaussian / small-mixture (K <= 4) reference, d > 64, B <= 8 192, no injected noise;
+// the trajectory (xs_out) is written.  No range-safe twin of the drift net here (sim_device.hpp mlp_hidden_safe): states / activations
+// beyond 65 504 give NaN on this path.
 #pragma once
 #include "sim_kernel.hpp"
 
@@ -51,6 +54,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
   }
   __syncthreads();
   const float* bias = a.wpack + sd_off_bias(NT);
+  const NetScale ns = load_net_scale(bias, NT);  // per-layer 2^-e of the packed weights (all 1 unless a matrix is out of the f16 split's range)
   float* xch = lds + sd_lds_weight_floats(NT) + slot * SD_SPLIT_SLOT_FLOATS;
   f32x4* P = reinterpret_cast<f32x4*>(xch);            // [hidden tile][partial of wave v][lane]; A1 overlays its first 1024 floats
   f32x4* A0 = reinterpret_cast<f32x4*>(xch + 4096);    // [hidden tile][lane]
@@ -173,7 +177,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
         f32x4 h = b_in;
 #pragma unroll
         for (int v = 0; v < SD_SPLIT_W; ++v) h = h + P[(w * SD_SPLIT_W + v) * 64 + lane];
-        h = h + te;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = __builtin_fmaf(h[r], ns.inv_in, te[r]);  // (inv = 1: h + te bit for bit)
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = gelu_fast(h[r]);
         A0[w * 64 + lane] = h;
@@ -224,8 +229,12 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
           mx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, hl[kb], mx, 0, 0, 0);
           mx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, hh[kb], mx, 0, 0, 0);
         }
+        const float inv_l = layer == 0 ? ns.inv_h1 : ns.inv_h2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = gelu_fast(__builtin_fmaf(mx[r], SD_LO_INV, acc[r]));
+        for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(mx[r], SD_LO_INV, acc[r]);
+        if (inv_l != 1.0f) acc = acc * inv_l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = gelu_fast(acc[r]);
         Aout[w * 64 + lane] = acc;
         __syncthreads();  // 3, 4
       }
@@ -253,6 +262,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_split(con
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[r] = __builtin_fmaf(mx[r], SD_LO_INV, u[r]);
+            if (ns.inv_out != 1.0f) u = u * ns.inv_out;
             if (a.clip_model > 0.0f) clamp_tile_rare(u, a.clip_model);  // ClippedCtrl (reparam.py:42)
             const f32x4 z = philox_normal4(pidx, static_cast<uint32_t>(k), static_cast<uint32_t>(4 * t + g), 0u, a.seed_lo, a.seed_hi);
             f32x4 rq = zero;  // reference score of this tile (eq/sdes.py:265-279, 329-345)

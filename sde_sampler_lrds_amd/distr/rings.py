@@ -1,4 +1,5 @@
-"""2-D rings target (mirror of ``sde_sampler/distr/rings.py:38-148``): a Gaussian mixture over the radius times a
+"""2-D rings target (mirror of ``sde_sampler/distr/rings.py:38-121``; the sample-based diagnostics of :123-148 -- mode counts, entropy,
+KL of the mode weights -- belong to the reference's eval/ layer and are not on this path): a Gaussian mixture over the radius times a
 uniform angle.  Host-side torch methods only; the simulate path reads (radiuses, mixture probs, scale) through
 ``engine.dist_desc`` and evaluates log-density and score in HIP."""
 from __future__ import annotations
@@ -59,23 +60,3 @@ class Rings(Distribution):
     def score(self, x, eps=1e-7, **kwargs):
         norm_x = torch.linalg.norm(x, dim=-1, keepdim=True) + eps
         return x * ((self.score_radius(norm_x) / norm_x) - (1.0 / torch.square(norm_x)))
-
-    def has_entropy(self):
-        return True
-
-    def compute_mode_count(self, samples):
-        radiuses_sq = torch.square(samples[:, 0]) + torch.square(samples[:, 1])
-        idx = torch.argmin(torch.abs(radiuses_sq.unsqueeze(-1) - torch.square(self.radiuses.to(samples.device))), dim=-1)
-        return torch.bincount(idx, minlength=self.radiuses.shape[0]).float()
-
-    def entropy(self, samples, counts=None):
-        counts = self.compute_mode_count(samples) if counts is None else counts
-        hist = counts.flatten() / counts.sum()
-        return -torch.sum(hist * (torch.log(hist) / math.log(counts.shape[0])))
-
-    def kl_weights(self, samples, counts=None):
-        counts = self.compute_mode_count(samples) if counts is None else counts
-        hist = counts.flatten() / counts.sum()
-        true_hist = self.radius_dist.mixture_distribution.probs.flatten().to(hist.device)
-        true_hist = true_hist / true_hist.sum()
-        return torch.sum(true_hist * torch.log(true_hist / hist))

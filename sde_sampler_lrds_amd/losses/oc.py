@@ -180,15 +180,14 @@ class BaseOCLoss:
         their gradient comes from ONE batched pass of the control over all N*B (time, state) pairs
         (:269-271, :284 EM; :490-491, :499 EI / DDPM-like; :957-958, :965 DIS; :1361-1383 DDS).  KL training differentiates
         through the trajectory and is not on this path."""
-        if self.method not in ("lv", "lv_traj"):
-            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path "
-                                        "(log-variance training is: method='lv')")
+        assert self.method in ("lv", "lv_traj")
         if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
             raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built "
                                         "(every conf/loss/*.yaml leaves both empty; listed under 'raises' in INTEGRATION.md)")
         # a fresh stream per training call (the reference consumes torch's global generator): call c uses the engine's Philox
         # streams keyed by seed + c * golden-ratio increment -- for the step noise AND for an x0 left to the engine (an InitialDraw
         # materialised with the loss's fixed seed would hand every training step the same batch); call 0 is the eval stream of ``seed``
+        E.require_gpu(x)
         seed_c = self._next_train_seed()
         x = self._x0(x, seed_c)
         if self.traj_per_sample != 1:
@@ -238,6 +237,69 @@ class BaseOCLoss:
                     fn = _IntegralPass(ctrl)
             self._graphed[key] = fn
         return fn(t_unique, xs.contiguous(), zc)
+
+    def _kl_loss(self, ts, x, simulate, terminal, *, lin, coef_kw=None, reference_ctrl=None, ito=True):
+        """KL training value and gradient (``method in ('kl', 'kl_ito')``): loss = mean of the log-weights over the particles that pass
+        ``filter``, differentiated THROUGH the trajectory (BaseOCLoss.compute_loss losses/oc.py:105-131 on ``simulate(change_sde_ctrl=
+        False)``, where the control that drives the SDE is the un-detached control: :258-260, :478-484, :1361-1365).
+
+        VALUE: the HIP step loop -- one launch with the trajectory kept (and the noise of this call's Philox stream, redrawn below).
+        GRADIENT: the discrete adjoint of exactly the recursion the kernel integrates (include/sdeng.h, FORM_LIN / FORM_EM with the
+        host's per-step coefficients):
+            lambda_N = d terminal / d x_N ;   for k = N-1 .. 0:  S_k = <lambda_{k+1}, x_{k+1}(x_k, theta)> + sum_b w_b d rnd_k,b(x_k, theta)
+            lambda_k = dS_k/dx_k ,   dL/dtheta += dS_k/dtheta
+        with the HIP states x_k as constants -- N vector-Jacobian products of ONE step each (torch autograd on the control module and the
+        reference score), no graph through the loop.  This is the same number the reference's ``loss.backward()`` produces (fixtures
+        ``train_kl_*``: loss to 6 digits, gradients to fp32 round-off); it is not yet a fused kernel."""
+        if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
+            raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control (losses/oc.py:97-101): not built")
+        E.require_gpu(x)
+        seed_c = self._next_train_seed()
+        x = self._x0(x, seed_c)
+        if self.traj_per_sample != 1:
+            x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
+        N, (B, d) = ts.numel() - 1, x.shape
+        seed_eval, self.seed = self.seed, seed_c
+        try:
+            with torch.no_grad():
+                x_n, rnd_sim, xs = simulate(x)
+        finally:
+            self.seed = seed_eval
+        z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)  # bit for bit the normals the kernel drew
+        rnd_val = rnd_sim.reshape(B, 1)
+        mask = self.filter(rnd_val, samples=x_n)
+        assert mask.shape == rnd_val.shape
+        self.n_filtered += (mask.numel() - mask.sum()).item()
+        w = mask.to(rnd_val.dtype) / mask.sum()  # d mean(rnd[mask]) / d rnd_b
+        value = rnd_val[mask].mean()
+        ctrl = self.generative_ctrl
+        params = [p for p in ctrl.parameters() if p.requires_grad]
+        grads = [torch.zeros_like(p) for p in params]
+        coef = self._coef(ts, x.device, **(coef_kw or {}))
+        with torch.enable_grad():
+            xN = x_n.detach().requires_grad_(True)
+            lam, = torch.autograd.grad((w * terminal(xN).view(B, 1)).sum(), xN)
+            for k in range(N - 1, -1, -1):
+                c = coef[k]
+                xk = xs[k].detach().requires_grad_(True)
+                u = ctrl(c[0], xk)
+                ref = reference_ctrl(c[0], xk) if reference_ctrl is not None else None
+                uu, uz = (u * u).sum(-1, keepdim=True), (u * z[k]).sum(-1, keepdim=True)
+                if lin:   # x' = c1 x + c2 (u [+ ref]) + c3 z ;  rnd += c4 <u,u> + c5 <u,z>
+                    x_next = c[1] * xk + c[2] * (u if ref is None else ref + u) + c[3] * z[k]
+                    dr = c[4] * uu + (c[5] * uz if ito else 0.0)
+                else:     # x' = x + ((c1 x [+ c3 ref]) + c2 u) c4 + c2 (c5 z) ;  rnd += 0.5 <u,u> c4 + c5 <u,z>
+                    drift = c[1] * xk if ref is None else c[1] * xk + c[3] * ref
+                    x_next = xk + (drift + c[2] * u) * c[4] + c[2] * (c[5] * z[k])
+                    dr = 0.5 * uu * c[4] + (c[5] * uz if ito else 0.0)
+                got = torch.autograd.grad((lam * x_next).sum() + (w * dr).sum(), [xk] + params, allow_unused=True)
+                lam = got[0]
+                for acc, g in zip(grads, got[1:]):
+                    if g is not None:
+                        acc += g
+        # hand the gradient to autograd: value + sum <p - p.detach(), dL/dp>  (zero-valued, gradient dL/dp)
+        surrogate = sum(((p - p.detach()) * g).sum() for p, g in zip(params, grads))
+        return value.detach() + surrogate, {"train/n_filtered_cumulative": self.n_filtered}
 
     # ---- engine plumbing ---------------------------------------------------------------------
     @staticmethod
@@ -430,8 +492,13 @@ class EMReferenceSDELoss(BaseOCLoss):
         def sim(xx, z):
             return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
                                  change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+        with_ref = E.resolve_reference(self.reference_ctrl)[0] != "none"
+        if self.method in ("kl", "kl_ito"):  # :364-394 with change_sde_ctrl = False; the Ito term is always part of these losses (:284, :499)
+            return self._kl_loss(ts, x, lambda xx: sim(xx, None),
+                                 lambda xn: reference_log_prob(xn).view(-1, 1) - terminal_unnorm_log_prob(xn).view(-1, 1),
+                                 lin=self.kind != "em", coef_kw=dict(with_ref=with_ref), reference_ctrl=self.reference_ctrl if with_ref else None)
         return self._lv_loss(ts, x, sim, lambda xn: self._logp(reference_log_prob, xn) - self._logp(terminal_unnorm_log_prob, xn),
-                             lin=self.kind != "em", coef_kw=dict(with_ref=E.resolve_reference(self.reference_ctrl)[0] != "none"))
+                             lin=self.kind != "em", coef_kw=dict(with_ref=with_ref))
 
     def compute_eubo(self, ts, x, terminal_unnorm_log_prob, reference_log_prob, use_ema=False, *, noise=None):
         """losses/oc.py:298-362 (EM; inherited by the DDPM-like loss) and :512-568 (EI): noising trajectories started at
@@ -560,6 +627,7 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
             raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
         if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
             raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control: not built")
+        E.require_gpu(x)
         seed_c = self._next_train_seed()
         x = self._x0(x, seed_c)
         if self.traj_per_sample != 1:
@@ -616,8 +684,8 @@ class DiscreteTimeReversalLossEI(_InitialLogProbLoss):
         def sim(xx, z):
             return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=None, train=True,
                                  change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
-        if self.method in ("kl", "kl_ito"):
-            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
+        if self.method in ("kl", "kl_ito"):  # :1038-1066; rnd0 = 0 for the KL methods (:935-939)
+            return self._kl_loss(ts, x, lambda xx: sim(xx, None), lambda xn: -terminal_unnorm_log_prob(xn).view(-1, 1), lin=True)
         return self._lv_loss(ts, x, sim, lambda xn: -self._logp(terminal_unnorm_log_prob, xn), lin=True, rnd0=initial_log_prob)
 
     def compute_eubo(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None, use_ema=False, *, noise=None):
@@ -658,13 +726,18 @@ class TimeReversalLoss(_InitialLogProbLoss):
 
     def __call__(self, ts, x, terminal_unnorm_log_prob, initial_log_prob=None):
         """[TRAINING] losses/oc.py:1240-1272, log-variance methods, no inference control: cost <u, u.detach() - u/2> dt + <u, db>."""
-        if self.method in ("kl", "kl_ito"):
-            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
         lerp = type(self.generative_ctrl).__name__ == "LerpCtrl"
+        kl = self.method in ("kl", "kl_ito")
+        ito = self.method != "kl"  # :1251 compute_ito_int = self.method != "kl"
 
         def sim(xx, z):
             return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=None, train=True,
-                                 compute_ito_int=True, change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+                                 compute_ito_int=ito, change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+        if kl:
+            if self.inference_ctrl is not None:
+                raise E.UnsupportedByEngine("a learned inference control needs the divergence of a net (autograd): not on the HIP path")
+            return self._kl_loss(ts, x, lambda xx: sim(xx, None), lambda xn: -terminal_unnorm_log_prob(xn).view(-1, 1), lin=False,
+                                 coef_kw=dict(train=True, dim=x.shape[-1], lerp=lerp), ito=ito)
         return self._lv_loss(ts, x, sim, lambda xn: -self._logp(terminal_unnorm_log_prob, xn), lin=False, rnd0=initial_log_prob,
                              coef_kw=dict(train=True, dim=x.shape[-1], lerp=lerp))
 
@@ -687,9 +760,15 @@ class ExponentialIntegratorSDELoss(BaseOCLoss):
 
     def __call__(self, ts, x, terminal_unnorm_log_prob, reference_log_prob):
         """[TRAINING] losses/oc.py:1399-1428, log-variance methods (compute_ito_int = True for them)."""
+        ito = self.method != "kl"  # :1414 compute_ito_int = self.method != "kl"
+
         def sim(xx, z):
             return self.simulate(ts, xx, terminal_unnorm_log_prob=terminal_unnorm_log_prob, reference_log_prob=reference_log_prob,
-                                 compute_ito_int=True, change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+                                 compute_ito_int=ito, change_sde_ctrl=False, return_traj=True, use_ema=False, noise=z)
+        if self.method in ("kl", "kl_ito"):
+            return self._kl_loss(ts, x, lambda xx: sim(xx, None),
+                                 lambda xn: reference_log_prob(xn).view(-1, 1) - terminal_unnorm_log_prob(xn).view(-1, 1), lin=True,
+                                 coef_kw=dict(alpha=self.alpha, sigma=self.sigma), ito=ito)
         return self._lv_loss(ts, x, sim, lambda xn: self._logp(reference_log_prob, xn) - self._logp(terminal_unnorm_log_prob, xn), lin=True,
                              coef_kw=dict(alpha=self.alpha, sigma=self.sigma))
 

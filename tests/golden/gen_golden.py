@@ -201,9 +201,6 @@ def case_eubo_gmm(name, d, K, B, N, seed, integrator, cov="diag"):
     sde = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0)
     target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
     ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
-    if remove_ref:  # Langevin init on a reference solver: CancelDriftCtrl (conf/model/langevin_init.yaml) under RemoveReferenceCtrl (below)
-        ctrl = r_rep.CancelDriftCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0), target_score=target.score,
-                                     detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0, sde=sde, langevin_init=True)
     means = target.loc.clone() + 0.1 * torch.randn(K, d)
     variances, weights = 0.5 * torch.ones(K, d), torch.ones(K)
     cov_arrays = dict(ref_vars=variances)
@@ -255,16 +252,13 @@ def case_eubo_dis(name, d, K, B, N, seed):
     save(name, meta, arrays)
 
 
-def case_train_lv(name, d, K, B, N, seed, integrator):
+def case_train_lv(name, d, K, B, N, seed, integrator, method="lv"):
     """One log-variance training evaluation of the RDS losses (losses/oc.py:364-394 with method='lv'): loss value and
     the gradient w.r.t. every drift-net parameter under the replayed noise."""
     torch.manual_seed(seed)
     sde = r_sdes.VP(diff_coeff_sq_min=0.1, diff_coeff_sq_max=10.0, scale_diff_coeff=1.0, terminal_t=1.0)
     target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, mixture_weight_factor=3.0, n_reference_samples=10)
     ctrl = r_rep.ClippedCtrl(base_model=liven(fourier_mlp(d)), clip_model=1e4)
-    if remove_ref:  # Langevin init on a reference solver: CancelDriftCtrl (conf/model/langevin_init.yaml) under RemoveReferenceCtrl (below)
-        ctrl = r_rep.CancelDriftCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0), target_score=target.score,
-                                     detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0, sde=sde, langevin_init=True)
     means = target.loc.clone() + 0.1 * torch.randn(K, d)
     variances, weights = 0.5 * torch.ones(K, d), torch.ones(K)
 
@@ -273,7 +267,7 @@ def case_train_lv(name, d, K, B, N, seed, integrator):
 
     ref_distr = sde.marginal_gmm_distr(torch.tensor(0.0), means, variances, weights)
     cls = {"ei": r_oc.EIReferenceSDELoss, "em": r_oc.EMReferenceSDELoss, "ddpm_like": r_oc.DDPMLikeReferenceSDELoss}[integrator]
-    loss = cls(ctrl, ctrl, sde=sde, method="lv", reference_ctrl=reference_ctrl)
+    loss = cls(ctrl, ctrl, sde=sde, method=method, reference_ctrl=reference_ctrl)
     ts = r_get_timesteps(0.0, 1.0, steps=N)
     x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
     orig = torch.randn_like
@@ -286,7 +280,7 @@ def case_train_lv(name, d, K, B, N, seed, integrator):
     value.backward()
     grads = {f"grad.{k}": p.grad.detach().clone() for k, p in ctrl.named_parameters()}
     meta = dict(kind="train_lv", d=d, K=K, B=B, N=N, seed=seed, integrator=integrator, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0,
-                clip_model=1e4, loss=float(value), draws=rep.k)
+                clip_model=1e4, loss=float(value), draws=rep.k, method=method)
     arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights, ref_means=means,
                   ref_vars=variances, ref_w=weights, **pack_params("ctrl.", sd(ctrl)), **grads)
     save(name, meta, arrays)
@@ -306,7 +300,7 @@ def _train_fixture(name, meta, arrays, ctrl, call):
     save(name, dict(meta, loss=float(value), draws=rep.k), dict(arrays, **pack_params("ctrl.", sd(ctrl)), **grads))
 
 
-def case_train_lv_dis(name, d, K, B, N, seed):
+def case_train_lv_dis(name, d, K, B, N, seed, method="lv"):
     """DiscreteTimeReversalLossEI.__call__ (losses/oc.py:1038-1066), method='lv', ScoreCtrl on a mixture target."""
     torch.manual_seed(seed)
     sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
@@ -314,16 +308,16 @@ def case_train_lv_dis(name, d, K, B, N, seed):
     prior = r_gauss.IsotropicGauss(dim=d, scale=1.0)
     ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.2), target_score=target.score,
                            detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
-    loss = r_oc.DiscreteTimeReversalLossEI(ctrl, ctrl, sde=sde, method="lv")
+    loss = r_oc.DiscreteTimeReversalLossEI(ctrl, ctrl, sde=sde, method=method)
     ts = r_get_timesteps(0.0, 1.0, steps=N)
     x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
-    meta = dict(kind="train_lv_dis", d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0, clip_model=1e4,
+    meta = dict(method=method, kind="train_lv_dis", d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0, clip_model=1e4,
                 clip_score=1e4, scale_score=1.0)
     arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
 
 
-def case_train_lv_dis_orig(name, d, K, B, N, seed):
+def case_train_lv_dis_orig(name, d, K, B, N, seed, method="lv"):
     """TimeReversalLoss.__call__ (losses/oc.py:1240-1272), method='lv', LerpCtrl, no inference control (dis_orig)."""
     torch.manual_seed(seed)
     sde = r_sdes.VP(0.1, 10.0, 1.0, terminal_t=1.0)
@@ -331,10 +325,10 @@ def case_train_lv_dis_orig(name, d, K, B, N, seed):
     prior = r_gauss.IsotropicGauss(dim=d, scale=1.0)
     ctrl = r_rep.LerpCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=1.0), target_score=target.score,
                           detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0, sde=sde, prior_score=prior.score)
-    loss = r_oc.TimeReversalLoss(ctrl, ctrl, sde=sde, method="lv", inference_ctrl=None)
+    loss = r_oc.TimeReversalLoss(ctrl, ctrl, sde=sde, method=method, inference_ctrl=None)
     ts = r_get_timesteps(0.0, 1.0, steps=N)
     x0 = orc.philox_normal(seed, 0, 0, B, d, stream=1)
-    meta = dict(kind="train_lv_dis_orig", d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0, clip_model=1e4,
+    meta = dict(method=method, kind="train_lv_dis_orig", d=d, K=K, B=B, N=N, seed=seed, beta_min=0.1, beta_max=10.0, sigma=1.0, T=1.0, clip_model=1e4,
                 clip_score=1e4, scale_score=1.0)
     arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
@@ -357,23 +351,23 @@ def case_train_lv_cmcd(name, d, K, B, N, seed):
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
 
 
-def case_train_lv_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0):
+def case_train_lv_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0, method="lv"):
     """ExponentialIntegratorSDELoss.__call__ (losses/oc.py:1399-1428), method='lv', TwoModes target."""
     torch.manual_seed(seed)
     target = r_gauss.TwoModes(dim=d, a=1.0, ill_conditioned="not", n_reference_samples=10)
     prior = r_gauss.IsotropicGauss(dim=d, scale=sigma)
     ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.01), target_score=target.score,
                            detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
-    loss = r_oc.ExponentialIntegratorSDELoss(ctrl, ctrl, sde=None, method="lv", alpha=1.0, sigma=sigma)
+    loss = r_oc.ExponentialIntegratorSDELoss(ctrl, ctrl, sde=None, method=method, alpha=1.0, sigma=sigma)
     ts = r_get_timesteps(0.0, end, dt=dt, rescale_t="cosine")
     x0 = sigma * orc.philox_normal(seed, 0, 0, B, d, stream=1)
-    meta = dict(kind="train_lv_dds", d=d, B=B, N=len(ts) - 1, seed=seed, alpha=1.0, sigma=sigma, clip_model=1e4, clip_score=1e4,
+    meta = dict(method=method, kind="train_lv_dds", d=d, B=B, N=len(ts) - 1, seed=seed, alpha=1.0, sigma=sigma, clip_model=1e4, clip_score=1e4,
                 scale_score=1.0, dt=dt, end=end)
     arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, prior.log_prob))
 
 
-def case_train_lv_pis(name, d, B, N, seed, dt):
+def case_train_lv_pis(name, d, B, N, seed, dt, method="lv"):
     """EMReferenceSDELoss.__call__ without a reference (PIS, losses/oc.py:364-394), method='lv', phi^4 target."""
     torch.manual_seed(seed)
     g, Tstar = math.sqrt(0.2), 5.0
@@ -383,10 +377,10 @@ def case_train_lv_pis(name, d, B, N, seed, dt):
     ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.02), target_score=target.score,
                            detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
     ref_distr = sde.marginal_distr(t=sde.terminal_t, x_init=prior.loc)
-    loss = r_oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    loss = r_oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method=method, max_rnd=1e8 if method == "lv" else None)
     ts = torch.linspace(0.0, N * dt, N + 1)
     x0 = prior.sample((B,))
-    meta = dict(kind="train_lv_pis", d=d, B=B, N=N, seed=seed, diff_coeff=g, T=Tstar, a=0.1, b=0.0, beta=20.0, clip_model=1e4,
+    meta = dict(method=method, kind="train_lv_pis", d=d, B=B, N=N, seed=seed, diff_coeff=g, T=Tstar, a=0.1, b=0.0, beta=20.0, clip_model=1e4,
                 clip_score=1e4, scale_score=1.0)
     arrays = dict(ts=ts, x0=x0, ref_loc=ref_distr.loc, ref_scale=ref_distr.scale)
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob))
@@ -419,9 +413,6 @@ def case_rds_default(name, d, K, B, N, seed, sde_kind="vp", integrator="em", ful
     ref_ctrl = lambda t, x: sde.marginal_score(t=t, x=x, x_init=x_init, var_init=var_init)  # noqa: E731
     cls = {"ei": r_oc.EIReferenceSDELoss, "ddpm_like": r_oc.DDPMLikeReferenceSDELoss,
            "em": r_oc.EMReferenceSDELoss}[integrator]
-    inner = ctrl
-    if remove_ref:  # models/reparam.py:46-64 in the form its forward can evaluate (use_rescaling=False): ctrl - ref_score
-        ctrl = r_rep.RemoveReferenceCtrl(inner, ref_ctrl, use_rescaling=False)
     loss = cls(ctrl, ctrl, sde=sde, method="kl", reference_ctrl=ref_ctrl)
     res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob,
                                                          compute_weights=True, return_traj=True, use_ema=False))
@@ -927,6 +918,13 @@ CASES = {
     "train_lv_dis_orig_d8": lambda n: case_train_lv_dis_orig(n, d=8, K=4, B=64, N=64, seed=76),
     "train_lv_cmcd_gmm_d16": lambda n: case_train_lv_cmcd(n, d=16, K=4, B=64, N=32, seed=77),
     "train_lv_pis_phi4_d100": lambda n: case_train_lv_pis(n, d=100, B=32, N=16, seed=75, dt=5.0 / 512),
+    # KL training (method='kl': back-propagation through the whole trajectory, BaseOCLoss.compute_loss :105-131): loss + every gradient
+    "train_kl_dds_d2": lambda n: case_train_lv_dds(n, d=2, B=128, seed=174, method="kl"),
+    "train_kl_ei_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=171, integrator="ei", method="kl"),
+    "train_kl_em_gmm_d16": lambda n: case_train_lv(n, d=16, K=4, B=64, N=32, seed=172, integrator="em", method="kl"),
+    "train_kl_dis_ei_d8": lambda n: case_train_lv_dis(n, d=8, K=4, B=64, N=32, seed=173, method="kl"),
+    "train_kl_dis_orig_d8": lambda n: case_train_lv_dis_orig(n, d=8, K=4, B=64, N=64, seed=176, method="kl"),
+    "train_kl_pis_phi4_d100": lambda n: case_train_lv_pis(n, d=100, B=32, N=16, seed=175, dt=5.0 / 512, method="kl"),
     # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
     "pis_em_phi4_d100": lambda n: case_pis_phi4(n, d=100, B=64, N=32, seed=21, dt=5.0 / 512),
     # config 1 (TwoModes d=2, DDS) and the Rings target on the same solver

@@ -64,4 +64,21 @@ def test_headline_kernels_keep_their_registers():
     assert cfg3[1] == 0 and cfg3[2] >= 3 and cfg3[0] <= 168, cfg3
     assert cfg4[1] == 0 and cfg4[2] >= 2, cfg4
     three = [(n, r) for n, r in rows.items() if n.startswith("_Z10k_simulateI") and r[2] == 3]
-    assert len(three) >= 30 and all(r[1] == 0 for _, r in three), [x for x in three if x[1][1]][:5]
+    spilled = [(n, r) for n, r in three if r[1]]
+    assert len(three) >= 30 and all(r[1] <= 16 for _, r in spilled), spilled[:5]
+    # A few bytes of scratch are tolerated only OUTSIDE the step loop (a loop-invariant parked before it): checked in the ISA -- no
+    # scratch instruction between the kernel's first and last matrix instruction.  (phi^4 at d = 128: 8 bytes since the range guard.)
+    units = {line.split()[0] for line in open(os.path.join(build.OBJ, "kernel_resources.txt")) if not line.startswith("#") and line.split()[1] in dict(spilled)}
+    for unit in sorted(units):
+        out = os.path.join(build.OBJ, unit.replace(".hip", ".s"))
+        r = subprocess.run([build.HIPCC, *build.FLAGS, "--cuda-device-only", "-S", os.path.join(build.GEN, unit), "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = open(out).read()
+        for name, _ in spilled:
+            if name + ":" not in text:
+                continue
+            body = text[text.index(name + ":"):]
+            body = body[:body.index(".Lfunc_end")].split("\n")
+            mfma = [i for i, l in enumerate(body) if "v_mfma" in l]
+            inside = [l.strip() for l in body[mfma[0]:mfma[-1]] if "scratch_" in l]
+            assert not inside, (name, inside[:3])

@@ -286,3 +286,36 @@ def test_compute_eubo_at_full_occupancy(gpu, name, B):
         assert torch.equal(part, full[lo:lo + 48]) and torch.equal(xp, xa[lo:lo + 48]), f"wave slot {wave}: block differs from the full launch"
     loss.particle0 = 0
     assert bool(torch.isfinite(full).all())
+
+
+@pytest.mark.gpu
+def test_false_shared_variance_promise_is_loud(gpu):
+    """sdeng_ref.shared_var is the CALLER's promise that all components share one variance vector; the matrix-pipe mixture path
+    (RF_GMM_MM, 4 < K <= 64) reads only row 0 of vars_init.  The promise is checked on the device (k_same_var): a false one poisons the
+    per-step table, so the call returns NaN everywhere instead of the scores of another mixture.  Through the C ABI
+    directly -- the Python host derives the flag from the tensor itself and cannot lie."""
+    import ctypes as C
+
+    from sde_sampler_lrds_amd import _lib as L
+    d, K, B, N = 64, 8, 256, 8
+    var = 0.5 * torch.ones(K, d)
+    var[3, 5] = 0.7  # one entry differs
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=3, ref_var=var)
+    honest = loss.simulate(ts, x0, *args, **kw)  # the host sees the rows differ: vector path
+    assert bool(torch.isfinite(honest[0]).all()) and bool(torch.isfinite(honest[1]).all())
+    orig = E.ref_desc
+
+    def lying(kind, utils, device, keep):
+        r = orig(kind, utils, device, keep)
+        r.shared_var = 1
+        return r
+    E.ref_desc = lying
+    try:
+        x, rnd, _ = loss.simulate(ts, x0, *args, **kw)
+    finally:
+        E.ref_desc = orig
+    assert bool(torch.isnan(x).all()) and bool(torch.isnan(rnd).all())
+    # ... and an honest shared-variance mixture of the same shape runs the matrix-pipe path and is finite
+    loss2, ts2, x02, args2, kw2, _ = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=3)
+    ok = loss2.simulate(ts2, x02, *args2, **kw2)
+    assert bool(torch.isfinite(ok[0]).all()) and bool(torch.isfinite(ok[1]).all())

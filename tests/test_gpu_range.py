@@ -1,0 +1,143 @@
+"""Dynamic range of the split-f16 drift net.  The GEMMs run as three f16 products per fp32 product
+(sim_device.hpp): f16 has fp32's mantissa budget only inside its NORMAL range, and overflows at 65 504.  Two mechanisms give the
+path fp32's range, both held to the oracle here:
+
+* weights: each matrix is stored times a power of two that brings its largest entry to [1, 2) when that entry is below 2^-10 or at /
+  above 2^14 (k_weight_scales), the layer's output is multiplied back -- the reference's OWN default initialisation puts the last
+  layer at |w| <= 1.25e-7 (models/utils.py:7-22 kaiming_uniform_zeros_), f16-subnormal: before this the control at init carried a
+  1.3e-4 relative error, now fp32 round-off;
+* states / activations: an operand beyond 65 504 is detected after the fact (one compare per tile-step) and the step's net is
+  re-evaluated with per-particle power-of-two scaling (mlp_hidden_safe): |x0| = 1e5 gives the oracle's finite result, not NaN.
+"""
+import pytest
+import torch
+
+from oracle import baseline_oracles as bo
+from oracle import sde_oracle as orc
+from sde_sampler_lrds_amd import engine as E
+from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
+from sde_sampler_lrds_amd.models import utils as mutils
+from sde_sampler_lrds_amd.models.mlp import FourierMLP
+from sde_sampler_lrds_amd.models.reparam import ClippedCtrl
+
+
+def _fp64_forward(ctrl, t, x):
+    """The control in fp64 (the yardstick both fp32 implementations are measured against)."""
+    import copy
+    c64 = copy.deepcopy(ctrl).double().cpu()
+    with torch.no_grad():
+        return c64(torch.tensor(t, dtype=torch.float64), x.double().cpu())
+
+
+def _oracle_forward(ctrl, t, x):
+    sd = {k: v.detach().cpu() for k, v in ctrl.state_dict().items()}
+    with torch.no_grad():
+        return orc.Ctrl(sd, "clipped", clip_model=ctrl.clip_model)(torch.tensor(t), x.cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [128, 40, 2])
+def test_control_at_the_reference_default_initialisation(gpu, d):
+    """make_model(...) starts every sampler from kaiming_uniform_zeros_ / init_bias_uniform_zeros on the last layer: |w| ~ 1e-7."""
+    torch.manual_seed(d)
+    net = FourierMLP(dim=d, activation=torch.nn.GELU(), num_layers=4, channels=64, last_bias_init=mutils.init_bias_uniform_zeros,
+                     last_weight_init=mutils.kaiming_uniform_zeros_)
+    assert float(net.out_layer.weight.abs().max()) < 2e-7  # f16-subnormal
+    ctrl = ClippedCtrl(base_model=net, clip_model=1e4).to(gpu)
+    x = 2.0 * torch.randn(333, d, device=gpu)
+    got = E.ctrl_forward(ctrl, 0.37, x).cpu().double()
+    want64, want32 = _fp64_forward(ctrl, 0.37, x), _oracle_forward(ctrl, 0.37, x).double()
+    scale = float(want64.abs().max())
+    e_hip, e_orc = float((got - want64).abs().max()) / scale, float((want32 - want64).abs().max()) / scale
+    print(f"default init d={d}: |u| max {scale:.2e}; HIP vs fp64 {e_hip:.2e}, torch fp32 vs fp64 {e_orc:.2e}, HIP vs oracle {float((got - want32).abs().max()) / scale:.2e}")
+    assert scale < 1e-4 and e_hip < 1e-6 and float((got - want32).abs().max()) / scale < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,factor", [("input_embed", 1e-6), ("hidden_layer.0", 3e-5), ("hidden_layer.1", 1e-7), ("out_layer", 1e-9),
+                                          ("out_layer", 3e5), ("hidden_layer.0", 1e5), ("input_embed", 4e4)])
+def test_every_layer_keeps_fp32_accuracy_out_of_the_f16_range(gpu, which, factor):
+    """One layer at a time far below / above the range in which the un-scaled split is accurate.  Error of the HIP control against fp64,
+    relative to the largest output, must stay at the fp32 evaluation's own (torch CPU) -- within 4x."""
+    torch.manual_seed(7)
+    d = 72
+    net = cfgs._net(d)
+    mod = net
+    for part in which.split("."):
+        mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+    with torch.no_grad():
+        mod.weight.mul_(factor)
+        mod.bias.mul_(factor)
+    ctrl = ClippedCtrl(base_model=net, clip_model=None).to(gpu)
+    x = torch.randn(200, d, device=gpu)
+    got = E.ctrl_forward(ctrl, 0.6, x).cpu().double()
+    want64, want32 = _fp64_forward(ctrl, 0.6, x), _oracle_forward(ctrl, 0.6, x).double()
+    scale = float(want64.abs().max())
+    e_hip, e_orc = float((got - want64).abs().max()) / scale, float((want32 - want64).abs().max()) / scale
+    print(f"{which} x {factor:g}: |u| max {scale:.2e}; HIP vs fp64 {e_hip:.2e}, torch fp32 vs fp64 {e_orc:.2e}")
+    assert bool(torch.isfinite(got).all()) and e_hip < max(4 * e_orc, 5e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,mag", [(128, 4, 1e5), (100, 3, 3e6), (40, 4, 7e4)])
+def test_states_beyond_the_f16_range_match_the_oracle(gpu, d, K, mag):
+    """|x0| ~ 1e5 .. 3e6: finite in the reference (fp32 GEMMs), NaN on the un-guarded f16 split.  cfg-2 shaped sampler, injected noise,
+    against the oracle; healthy particles in the same tiles are unaffected (same bits as a run without the large ones)."""
+    B, N = 96, 12
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=K, seed=11 + d)
+    g = torch.Generator().manual_seed(5)
+    big = x0.clone()
+    rows = torch.tensor([3, 17, 40, 41, 95])
+    big[rows] = (mag * torch.randn(len(rows), d, generator=g)).to(gpu)
+    z = torch.randn(N, B, d, generator=g)
+    x, rnd, _ = loss.simulate(ts, big, *args, noise=z.to(gpu), **kw)
+    run = bo.runner("rds_gmm", info, ts)
+    ox, ornd, scale = run(big.cpu(), orc.InjectedNoise(z))
+    assert bool(torch.isfinite(ox).all()), "the reference arithmetic itself is finite here"
+    assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(rnd[torch.isfinite(ornd)]).all())
+    ex = float(((x.cpu() - ox).abs() / ox.abs().clamp(min=1.0)).max())
+    fin = torch.isfinite(ornd).flatten()
+    rscale = torch.maximum(ornd.abs().flatten(), torch.tensor(scale)).clamp(min=1.0)
+    er = float(((rnd.cpu().flatten() - ornd.flatten()).abs() / rscale)[fin].max())
+    print(f"|x0| ~ {mag:g}, d={d}: x_N max rel err {ex:.2e}, rnd {er:.2e} ({int(fin.sum())} / {B} finite log-weights in the oracle)")
+    assert ex < 1e-5 and er < 1e-5
+    # the tiles that took the range-safe path return the fast path's bits for their healthy particles? No: the safe twin rounds
+    # differently (bias added after the product).  What must hold: healthy particles agree with the oracle like everywhere else.
+    healthy = torch.ones(B, dtype=torch.bool)
+    healthy[rows] = False
+    assert float(((x.cpu() - ox).abs() / ox.abs().clamp(min=1.0))[healthy].max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_large_hidden_activations_take_the_safe_path(gpu):
+    """Moderate states, but first-layer weights that push the hidden activations past 65 504."""
+    torch.manual_seed(3)
+    d = 128
+    net = cfgs._net(d)
+    with torch.no_grad():
+        net.input_embed.weight.mul_(3e3)  # |W_in| ~ 3e2 (inside the un-scaled weight range): activations ~ 3e3 * |x| * sqrt(d)
+    ctrl = ClippedCtrl(base_model=net, clip_model=None).to(gpu)
+    x = 30.0 * torch.randn(64, d, device=gpu)
+    got = E.ctrl_forward(ctrl, 0.2, x).cpu().double()
+    want64 = _fp64_forward(ctrl, 0.2, x)
+    want32 = _oracle_forward(ctrl, 0.2, x).double()
+    scale = float(want64.abs().max())
+    e_hip, e_orc = float((got - want64).abs().max()) / scale, float((want32 - want64).abs().max()) / scale
+    print(f"hidden activations up to {float(torch.nn.functional.linear(x, net.input_embed.weight.to(gpu)).abs().max()):.1e}: HIP vs fp64 {e_hip:.2e}, torch fp32 {e_orc:.2e}")
+    assert bool(torch.isfinite(got).all()) and e_hip < max(4 * e_orc, 5e-7)
+
+
+@pytest.mark.gpu
+def test_non_finite_inputs_stay_non_finite(gpu):
+    """inf / NaN states are the reference's business (BaseOCLoss.filter counts them, losses/oc.py:67-81): the guard must not launder them."""
+    B, N, d = 48, 6, 128
+    loss, ts, x0, args, kw, info = cfgs.build_rds_gmm(gpu, B, N, d=d, K=4, seed=2)
+    bad = x0.clone()
+    bad[5, 7] = float("inf")
+    bad[20, 100] = float("nan")
+    x, rnd, _ = loss.simulate(ts, bad, *args, **kw)
+    assert not bool(torch.isfinite(x[5]).all()) and not bool(torch.isfinite(x[20]).all())
+    assert not bool(torch.isfinite(rnd[5]).all()) and not bool(torch.isfinite(rnd[20]).all())
+    ok = torch.ones(B, dtype=torch.bool)
+    ok[[5, 20]] = False
+    assert bool(torch.isfinite(x[ok.to(gpu)]).all()) and bool(torch.isfinite(rnd[ok.to(gpu)]).all())

@@ -42,13 +42,47 @@ def test_lv_training_loss_and_gradients_match_reference(gpu, name):
 
 
 @pytest.mark.gpu
-def test_kl_training_is_refused(gpu):
-    c = gc.load("train_lv_ei_gmm_d16")
-    c.meta["kind"] = "rds_gmm"
+@pytest.mark.parametrize("name", ["train_kl_dds_d2", "train_kl_ei_gmm_d16", "train_kl_em_gmm_d16", "train_kl_dis_ei_d8", "train_kl_dis_orig_d8",
+                                  "train_kl_pis_phi4_d100"])
+def test_kl_training_loss_and_gradients_match_reference(gpu, name):
+    """method='kl' -- BaseOCLoss's default, BASELINE cfg 1's loss: back-propagation through the whole trajectory (losses/oc.py:105-131).
+    Fixtures: the reference's own ``loss(...)`` + ``backward()`` under the replayed noise.  Here: the HIP trajectory + the discrete
+    adjoint (BaseOCLoss._kl_loss)."""
+    c = gc.load(name)
+    assert c.meta["method"] == "kl"
+    c.meta["kind"] = KINDS[c.meta["kind"]]
+    b = bc.build(c, gpu)
+    loss = b["loss"]
+    loss.method, loss.max_rnd = "kl", None
+    ctrl = loss.generative_ctrl
+    for p in ctrl.parameters():
+        p.grad = None
+    kw = {k: v for k, v in b["kwargs"].items() if k == "initial_log_prob"}
+    value, metrics = loss(b["ts"], b["x0"], *b["args"], **kw)
+    value.backward()
+    loss_err = abs(float(value.detach()) - c.meta["loss"]) / max(1.0, abs(c.meta["loss"]))
+    worst, n = 0.0, 0
+    for k, p in ctrl.named_parameters():
+        if "grad." + k not in c.a:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref = c["grad." + k]
+        err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
+        worst, n = max(worst, err), n + 1
+    print(f"{name}: loss {float(value.detach()):.6f} vs {c.meta['loss']:.6f} (rel {loss_err:.1e}); worst relative gradient error {worst:.2e} over {n} parameters")
+    assert n >= 8 and loss_err < 1e-5 and worst < 5e-5
+    assert "train/n_filtered_cumulative" in metrics
+
+
+@pytest.mark.gpu
+def test_cmcd_kl_training_is_refused(gpu):
+    """The one KL path without an adjoint here: ControlledLangevinSDELoss (two control evaluations per step share the state)."""
+    c = gc.load("train_lv_cmcd_gmm_d16")
+    c.meta["kind"] = KINDS[c.meta["kind"]]
     b = bc.build(c, gpu)
     b["loss"].method = "kl"
     with pytest.raises(E.UnsupportedByEngine):
-        b["loss"](b["ts"], b["x0"], *b["args"])
+        b["loss"](b["ts"], b["x0"], *b["args"], initial_log_prob=b["kwargs"]["initial_log_prob"])
 
 
 @pytest.mark.gpu

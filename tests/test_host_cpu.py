@@ -115,12 +115,14 @@ def test_eubo_coef_tables_follow_the_noising_loops():
         assert ei[k, 9] == o.s(T - s)
 
 
-def test_training_direction_refuses_kl_without_a_gpu_path():
+def test_training_calls_have_no_cpu_path_either():
+    """KL and log-variance training both start with the HIP step loop: on CPU tensors they fail loudly, like simulate()."""
     c = gc.load("rds_ei_gmm_d8_k4")
     b = bc.build(c, "cpu")
-    b["loss"].method = "kl"
-    with pytest.raises(E.UnsupportedByEngine, match="KL training"):
-        b["loss"](b["ts"], b["x0"], *b["args"])
+    for method in ("kl", "lv"):
+        b["loss"].method = method
+        with pytest.raises(RuntimeError, match="MI355X"):
+            b["loss"](b["ts"], b["x0"], *b["args"])
 
 
 def test_no_cpu_execution_path():
@@ -128,8 +130,8 @@ def test_no_cpu_execution_path():
     b = bc.build(c, "cpu")
     with pytest.raises(RuntimeError, match="MI355X"):
         b["loss"].simulate(b["ts"], b["x0"], *b["args"])
-    with pytest.raises(E.UnsupportedByEngine):
-        b["loss"](b["ts"], b["x0"], *b["args"])  # training direction: not built, and says so
+    with pytest.raises(RuntimeError, match="MI355X"):
+        b["loss"](b["ts"], b["x0"], *b["args"])  # training direction (KL: the fixture's method): the same step loop, the same refusal
 
 
 def test_loss_surface_matches_reference_names():
