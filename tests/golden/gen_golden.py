@@ -297,7 +297,33 @@ def _train_fixture(name, meta, arrays, ctrl, call):
         torch.randn_like = orig
     value.backward()
     grads = {f"grad.{k}": p.grad.detach().clone() for k, p in ctrl.named_parameters() if p.grad is not None}
-    save(name, dict(meta, loss=float(value), draws=rep.k), dict(arrays, **pack_params("ctrl.", sd(ctrl)), **grads))
+    # How well-conditioned is this gradient?  The same call with every normal moved by +-1.2e-6 (what separates the kernel's hardware
+    # Box-Muller from libm's; random signs): the largest relative change of any parameter's gradient, in the REFERENCE's own arithmetic.
+    # Tests of an fp32 implementation assert max(5e-5, 10 x this).
+    from oracle.baseline_oracles import PerturbedNoise
+    sens = 0.0
+    for salt in range(2):
+        for p in ctrl.parameters():
+            p.grad = None
+        base = Replay(meta["seed"])
+        pert = PerturbedNoise(lambda k, x: orc.philox_normal(meta["seed"], k, 0, x.shape[0], x.shape[1]), salt=salt)
+        state = {"k": 0}
+
+        def draw(x, *a, **kw):
+            zz = pert(state["k"], x)
+            state["k"] += 1
+            return zz
+        torch.randn_like = draw
+        try:
+            v2, _ = call()
+        finally:
+            torch.randn_like = orig
+        v2.backward()
+        for k, p in ctrl.named_parameters():
+            if p.grad is not None and f"grad.{k}" in grads:
+                g0 = grads[f"grad.{k}"]
+                sens = max(sens, float((p.grad - g0).abs().max()) / max(float(g0.abs().max()), 1e-6))
+    save(name, dict(meta, loss=float(value), draws=rep.k, grad_sensitivity=sens), dict(arrays, **pack_params("ctrl.", sd(ctrl)), **grads))
 
 
 def case_train_lv_dis(name, d, K, B, N, seed, method="lv"):

@@ -95,17 +95,27 @@ def test_states_beyond_the_f16_range_match_the_oracle(gpu, d, K, mag):
     ox, ornd, scale = run(big.cpu(), orc.InjectedNoise(z))
     assert bool(torch.isfinite(ox).all()), "the reference arithmetic itself is finite here"
     assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(rnd[torch.isfinite(ornd)]).all())
-    ex = float(((x.cpu() - ox).abs() / ox.abs().clamp(min=1.0)).max())
+    # A state of 1e5 is pulled back to O(1) within a few steps by the reference drift: the fp32 round-off it carried while it was large
+    # (1e5 x 6e-8 per operation) is then a RELATIVE error of 1e-3 .. 1e-2 of the end point -- in the reference's own arithmetic.  Per
+    # particle: what a one-ulp relative change of x0 does to the oracle's x_N; the tolerance is max(1e-5, 10 x that), as everywhere.
+    px, prnd, _ = run(big.cpu() * (1.0 + 1.2e-7), orc.InjectedNoise(z))
+    rel = lambda a, b: ((a - b).abs() / b.abs().clamp(min=1.0)).amax(dim=1)  # noqa: E731
+    sens = rel(px, ox)
+    tol = torch.clamp(10 * sens, min=1e-5)
+    ex = rel(x.cpu(), ox)
     fin = torch.isfinite(ornd).flatten()
     rscale = torch.maximum(ornd.abs().flatten(), torch.tensor(scale)).clamp(min=1.0)
-    er = float(((rnd.cpu().flatten() - ornd.flatten()).abs() / rscale)[fin].max())
-    print(f"|x0| ~ {mag:g}, d={d}: x_N max rel err {ex:.2e}, rnd {er:.2e} ({int(fin.sum())} / {B} finite log-weights in the oracle)")
-    assert ex < 1e-5 and er < 1e-5
-    # the tiles that took the range-safe path return the fast path's bits for their healthy particles? No: the safe twin rounds
-    # differently (bias added after the product).  What must hold: healthy particles agree with the oracle like everywhere else.
+    er = ((rnd.cpu().flatten() - ornd.flatten()).abs() / rscale)
+    rsens = ((prnd.flatten() - ornd.flatten()).abs() / rscale)
     healthy = torch.ones(B, dtype=torch.bool)
     healthy[rows] = False
-    assert float(((x.cpu() - ox).abs() / ox.abs().clamp(min=1.0))[healthy].max()) < 1e-5
+    print(f"|x0| ~ {mag:g}, d={d}: large particles x_N rel err {float(ex[rows].max()):.2e} (own one-ulp sensitivity {float(sens[rows].max()):.2e}), "
+          f"healthy particles {float(ex[healthy].max()):.2e}; rnd {float(er[fin].max()):.2e} (sensitivity {float(rsens[fin].max()):.2e}); "
+          f"{int(fin.sum())} / {B} finite log-weights in the oracle")
+    assert bool((ex <= tol).all()), (ex / tol).max()
+    assert bool((er[fin] <= torch.clamp(10 * rsens[fin], min=1e-5)).all())
+    # healthy particles sharing a tile with a large one went through the range-safe twin too: same 1e-5 as everywhere
+    assert float(ex[healthy].max()) < 1e-5
 
 
 @pytest.mark.gpu

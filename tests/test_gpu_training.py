@@ -69,8 +69,13 @@ def test_kl_training_loss_and_gradients_match_reference(gpu, name):
         ref = c["grad." + k]
         err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
         worst, n = max(worst, err), n + 1
-    print(f"{name}: loss {float(value.detach()):.6f} vs {c.meta['loss']:.6f} (rel {loss_err:.1e}); worst relative gradient error {worst:.2e} over {n} parameters")
-    assert n >= 8 and loss_err < 1e-5 and worst < 5e-5
+    # tolerance: 5e-5 (10 x the worst achieved on the well-conditioned fixtures), or 10 x the fixture's own conditioning -- how far the
+    # REFERENCE's gradient moves when every normal is perturbed by 1.2e-6, recorded by gen_golden.py (train_kl_dds_d2: 1.0e-4, the
+    # sharp TwoModes target; the others ~1e-6)
+    tol = max(5e-5, 10 * c.meta.get("grad_sensitivity", 0.0))
+    print(f"{name}: loss {float(value.detach()):.6f} vs {c.meta['loss']:.6f} (rel {loss_err:.1e}); worst relative gradient error {worst:.2e} over {n} "
+          f"parameters (tolerance {tol:.1e}; reference's own sensitivity {c.meta.get('grad_sensitivity', 0.0):.1e})")
+    assert n >= 8 and loss_err < 1e-5 and worst < tol
     assert "train/n_filtered_cumulative" in metrics
 
 
