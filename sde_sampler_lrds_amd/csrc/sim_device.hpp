@@ -238,6 +238,7 @@ SD_INLINE void gelu_tiles(f32x4 (&v)[T]) {
 // All 1.0 for a net whose weights sit in the f16 split's good range -- then nothing below changes a bit of the result.
 struct NetScale {
   float inv_in, inv_h1, inv_h2, inv_out, s_in;
+  SD_INLINE bool any() const { return (inv_in != 1.0f) | (inv_h1 != 1.0f) | (inv_h2 != 1.0f) | (inv_out != 1.0f); }
 };
 SD_INLINE NetScale load_net_scale(const float* bias, int NT) {
   const float* sc = bias + 3 * 64 + 16 * NT;  // uniform address: scalar loads, loop invariant
@@ -257,30 +258,26 @@ SD_INLINE void unscale_tiles(f32x4 (&v)[T], float inv) {
 // returns gelu(h) (64 channels = 4 register tiles); mlp_out_tiles() produces OT 16-feature tiles of out_layer,
 // which the caller consumes (clip, cost, integrator) before asking for the next.  `temb` = this step's time
 // embedding [64] (hoisted: the reference recomputes the identical row for every particle, :136-137).
+// (The step loop calls this plain form only for a net whose four layer scales are all 1 -- NetScale::any() false; a scaled net runs
+// the range-safe twin below, which applies the scales: the common case carries no test per layer.)
 template <int NT>
 SD_INLINE void mlp_hidden(const f32x4 (&x)[NT], f32x4 (&a)[SD_HT], const float* lds, const float* bias, const float* temb,
-                          int lane, const NetScale& ns) {
+                          int lane) {
   const int g = lane >> 4;
   f32x4 b[SD_HT];
 #pragma unroll
-  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias, t, g);  // b_in (times the layer's scale, like the weights)
+  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias, t, g);  // b_in
   dense<NT, SD_HT>(x, a, lds + sd_off_win(NT), lane);
 #pragma unroll
-  for (int t = 0; t < SD_HT; ++t) {  // embed = embed_x + embed_t; the input layer's 2^-e rides on the add (fma(v, 1, t) = v + t bit for bit)
-    const f32x4 te = load_tile4(temb, t, g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a[t][r] = __builtin_fmaf(a[t][r], ns.inv_in, te[r]);
-  }
+  for (int t = 0; t < SD_HT; ++t) a[t] = a[t] + load_tile4(temb, t, g);  // embed = embed_x + embed_t
   gelu_tiles<SD_HT>(a);
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) b[t] = load_tile4(bias + 64, t, g);  // b_h1
   dense<SD_HT, SD_HT>(a, b, lds + sd_off_wh1(NT), lane);
-  unscale_tiles<SD_HT>(b, ns.inv_h1);
   gelu_tiles<SD_HT>(b);
 #pragma unroll
   for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias + 128, t, g);  // b_h2
   dense<SD_HT, SD_HT>(b, a, lds + sd_off_wh2(NT), lane);
-  unscale_tiles<SD_HT>(a, ns.inv_h2);
   gelu_tiles<SD_HT>(a);
 }
 
@@ -376,7 +373,7 @@ SD_INLINE HidSplit split_hidden(const f32x4 (&a)[SD_HT]) {
   return s;
 }
 template <int NT, int OT>
-SD_INLINE void mlp_out_tiles(const HidSplit& hs, const float* lds, const float* bias, int t0, int lane, f32x4 (&u)[OT], float inv_out) {
+SD_INLINE void mlp_out_tiles(const HidSplit& hs, const float* lds, const float* bias, int t0, int lane, f32x4 (&u)[OT], float inv_out = 1.0f) {
   const int g = lane >> 4;
   f32x4 mx[OT];
 #pragma unroll

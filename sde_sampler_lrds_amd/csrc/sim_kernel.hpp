@@ -126,6 +126,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
   static_assert(SC != SC_LOGREG || (REF == RF_NONE && NT <= 4), "in-loop logistic-regression score: no reference, d <= 64");
   const float* bias = a.wpack + sd_off_bias(NT);
   const NetScale ns = load_net_scale(bias, NT);
+  const bool scaled_net = ns.any();
   // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)
 #ifdef SD_DBG_NODMA
   constexpr bool ref_lds = false;
@@ -229,10 +230,13 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       // -- hidden layers 2, the whole tail (output layer, noise, integrator) 1, scores and bookkeeping 0 -- are worth another 2.4 %
       // (4.74 -> 4.63, 15.22 -> 14.86): profiles/r02_issue_priority.log.
       __builtin_amdgcn_s_setprio(2);
-      mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane, ns);
+      mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
       __builtin_amdgcn_s_setprio(1);
       HidSplit hs = split_hidden(hid);
-      // range guard (sim_device.hpp mlp_hidden_safe): set by the first output tile of the step when an f16 operand overflowed
+      // The range-safe twin of the net (sim_device.hpp mlp_hidden_safe) takes over -- at the first output tile of the step, below --
+      // when an f16 operand overflowed or when a weight matrix is stored with a power-of-two scale (wave-uniform, fixed for the
+      // launch: e.g. the reference's default initialisation; the plain pass above is then wasted work, for as long as the net sits
+      // there).  A healthy net with in-range weights pays one compare per step.
       bool safe_net = false;
       float hid_rs = 1.0f;
 
@@ -473,17 +477,17 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
         constexpr int OT = decltype(otc)::value;
         f32x4 u[OT];
         if (__builtin_expect(safe_net, 0)) mlp_out_tiles_safe<NT, OT>(hs, hid_rs, lds, bias, t0, lane, u, ns.inv_out);
-        else mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u, ns.inv_out);
+        else mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
         // (not in the kernels whose reference / target score puts the state itself through split-f16 products -- matrix-pipe and
         // full-covariance mixtures, the in-loop logistic-regression score: those products have no twin, the guard would be half a guard)
         constexpr bool range_guard = REF != RF_GMM_MM && REF != RF_GMM_FULL && SC != SC_LOGREG;
-        if (range_guard && t0 == 0) {
+        if (t0 == 0) {
           // A state or an activation beyond f16's range (65 504) turned into inf in a split operand: every output of that particle is
           // then inf or NaN, so ONE compare on the first output register finds it.  The net of this step is evaluated again through
           // the range-safe twin (per-particle power-of-two scaling of every layer's input) -- x has not been touched yet.  The
           // reference's fp32 GEMMs stay finite there, and so does this; inputs that are non-finite themselves stay non-finite.
-          const bool bad = !(__builtin_fabsf(u[0][0]) <= 3.0e38f);
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+          const bool bad = range_guard && !(__builtin_fabsf(u[0][0]) <= 3.0e38f);
+          if (__builtin_expect(scaled_net || __builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
             asm volatile("" ::: "memory");  // nothing of the cold path is to be prepared ahead of this test
             safe_net = true;
             mlp_hidden_safe<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane, ns);
@@ -616,9 +620,9 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
     load_rows<NT>(a.x_in, row, a.d, live, g, x);
     const float score_gain = a.coef[7], lerp_w = a.coef[8];
     f32x4 hid[SD_HT];
-    mlp_hidden<NT>(x, hid, lds, bias, a.temb, lane, ns);
+    mlp_hidden<NT>(x, hid, lds, bias, a.temb, lane);
     HidSplit hs = split_hidden(hid);
-    bool safe_net = false;  // range guard, as in the step loop
+    bool safe_net = false;  // scaled weights or an overflowed f16 operand: the range-safe twin, as in the step loop
     float hid_rs = 1.0f;
     f32x4 ts[SC != SC_NONE ? NT : 1];
     if constexpr (SC == SC_GMM) {
@@ -633,10 +637,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_forward(const
     for (int t = 0; t < NT; ++t) {
       f32x4 u[1];
       if (safe_net) mlp_out_tiles_safe<NT, 1>(hs, hid_rs, lds, bias, t, lane, u, ns.inv_out);
-      else mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, u, ns.inv_out);
+      else mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, u);
       if (t == 0) {
         const bool bad = !(__builtin_fabsf(u[0][0]) <= 3.0e38f);
-        if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+        if (ns.any() || __builtin_amdgcn_ballot_w64(bad) != 0) {
           safe_net = true;
           mlp_hidden_safe<NT>(x, hid, lds, bias, a.temb, lane, ns);
           hid_rs = split_hidden_safe(hid, hs);
