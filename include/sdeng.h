@@ -273,6 +273,18 @@ int sdeng_philox_normal(uint64_t seed, int32_t step, int64_t particle0, int32_t 
 int sdeng_philox_normal_steps(uint64_t seed, int32_t step0, int32_t n_steps, int64_t particle0, int32_t B, int32_t d,
                               uint32_t stream_id, float* out, void* stream);
 
+/* Training direction: fused forward + backward of the drift net -- FourierMLP under ClippedCtrl -- over
+ * M = n_times * rows_per_time rows; row r = k * rows_per_time + b is the state x[r] at time desc->coef[k][0].  Replaces the autograd
+ * graph that losses/oc.py:83-103 (generative_and_sde_ctrl) builds per step and loss.backward() walks (models/mlp.py:135-143,
+ * models/reparam.py:33-43).  Reads desc->{abi_version, d, coef, net, workspace}.  `cot` [M,d] is the cotangent of the control u.
+ * Per-row outputs, all [M,64] unless noted:  a0, a1, a2 = gelu of the three hidden pre-activations;  d0, d1, d2 = cotangents of those
+ * pre-activations;  dout [M,d] = cot under ClippedCtrl's clip mask;  gx [M,d] (optional) = gradient w.r.t. the state.  The
+ * parameter gradients are the caller's six products over the rows: dW_out = dout^T a2, dW_2 = d2^T a1, dW_1 = d1^T a0,
+ * dW_in = d0^T x, bias gradients = column sums, cotangent of the time embedding of time k = sum over its rows of d0. */
+int sdeng_ctrl_vjp(const sdeng_desc* desc, int32_t n_times, int32_t rows_per_time, const float* x, const float* cot, float* a0, float* a1,
+                   float* a2, float* d0, float* d1, float* d2, float* dout, float* gx, void* stream);
+size_t sdeng_ctrl_vjp_workspace_bytes(int32_t d, int32_t n_times);
+
 /* prior.sample((B,)) on the device, out[B,d]: exactly the x0 that sdeng_simulate draws for x_in == NULL with the same
  * (dist, seed, particle0).  Replaces IsotropicGauss.sample / Gauss.sample / Delta.sample / GaussFull.sample (distr/gauss.py:772-787,
  * 235-239, 709-713; distr/delta.py:27-31). */

@@ -45,6 +45,10 @@ def sources():
     os.makedirs(GEN, exist_ok=True)
     srcs = [os.path.join(CSRC, "sdeng_api.hip"), os.path.join(CSRC, "prep_kernels.hip"), os.path.join(CSRC, "cmcd_inst.hip"),
             os.path.join(CSRC, "euler_inst.hip")]
+    for dt in DTS:  # fused forward + backward of the drift net (grad_kernel.hpp): the training direction's batched control pass
+        path = os.path.join(GEN, f"vjp_{dt}.hip")
+        _write_if_changed(path, '#include "../grad_kernel.hpp"\n' + f"SD_DEFINE_VJP({dt})\n")
+        srcs.append(path)
     for dt in DTS:  # CMCD kernels (3 target kinds each)
         path = os.path.join(GEN, f"cmcd_{dt}.hip")
         _write_if_changed(path, '#include "../cmcd_kernel.hpp"\n'

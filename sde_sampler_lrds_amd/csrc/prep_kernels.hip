@@ -51,9 +51,9 @@ __global__ void __launch_bounds__(256) k_weight_scales(PackArgs a) {
 
 __global__ void k_pack_mlp(PackArgs a) {
   const int NT = a.NT;
-  const float* scales = a.out + sd_off_scales(NT);  // written by k_weight_scales, launched ahead of this kernel
+  const float* scales = a.transpose ? a.scales : a.out + sd_off_scales(NT);  // written by k_weight_scales, launched ahead of this kernel
   const int n_half = sd_lds_weight_floats(NT) * 2;
-  const int n_bias = 3 * 64 + 16 * NT;
+  const int n_bias = a.transpose ? 0 : 3 * 64 + 16 * NT;
   _Float16* img = reinterpret_cast<_Float16*>(a.out);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_half + n_bias; idx += gridDim.x * blockDim.x) {
     if (idx < n_half) {
@@ -77,7 +77,15 @@ __global__ void k_pack_mlp(PackArgs a) {
       const int kb = blk % KB, to = blk / KB;
       const int o = 16 * to + (lane & 15);
       const int i = 16 * (2 * kb + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
-      const float w = (o < n_out && i < n_in) ? W[static_cast<size_t>(o) * n_in + i] * scales[layer] : 0.0f;  // power of two: exact
+      float w = 0.0f;
+      if (o < n_out && i < n_in) {
+        if (!a.transpose) {
+          w = W[static_cast<size_t>(o) * n_in + i] * scales[layer];  // power of two: exact
+        } else {  // slot `layer` holds the transpose of matrix 3 - layer, stored [n_in x n_out] row-major
+          const float* Wt = layer == 0 ? a.w_out : (layer == 1 ? a.w_h2 : (layer == 2 ? a.w_h1 : a.w_in));
+          w = Wt[static_cast<size_t>(i) * n_out + o] * scales[3 - layer];
+        }
+      }
       const _Float16 hi = static_cast<_Float16>(w);
       img[idx] = part == 0 ? hi : static_cast<_Float16>((w - static_cast<float>(hi)) * 2048.0f);
     } else {
@@ -912,8 +920,8 @@ int sd_launch_sample_x0(const sdeng_dist& ds, unsigned lo, unsigned hi, long lon
 
 // ---- host-side launch wrappers -------------------------------------------------------------------
 int sd_launch_pack(const PackArgs& a, hipStream_t s) {
-  const int total = sd_lds_weight_floats(a.NT) * 2 + 3 * 64 + 16 * a.NT;
-  hipLaunchKernelGGL(k_weight_scales, dim3(1), dim3(256), 0, s, a);
+  const int total = sd_lds_weight_floats(a.NT) * 2 + (a.transpose ? 0 : 3 * 64 + 16 * a.NT);
+  if (!a.transpose) hipLaunchKernelGGL(k_weight_scales, dim3(1), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_pack_mlp, dim3((total + 255) / 256), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }

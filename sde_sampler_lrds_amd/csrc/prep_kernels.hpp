@@ -9,6 +9,11 @@ struct PackArgs {
   int NT, d;
   const float *w_in, *b_in, *w_h1, *b_h1, *w_h2, *b_h2, *w_out, *b_out;
   float* out;
+  // transpose = 1: the image of the TRANSPOSED net for the backward products (grad_kernel.hpp): slot of W_in <- W_out^T, W_1 <- W_2^T,
+  // W_2 <- W_1^T, W_out <- W_in^T, each with the power-of-two scale of its own matrix, read from `scales` (the forward image's
+  // scale block); no biases.  transpose = 0: `scales` is ignored (the forward pack computes and stores them).
+  int transpose;
+  const float* scales;
 };
 
 struct TimeEmbedArgs {

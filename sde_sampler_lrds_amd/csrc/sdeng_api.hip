@@ -13,6 +13,7 @@
 #include "prep_kernels.hpp"
 #include "sim_common.hpp"
 #include "cmcd_kernel.hpp"
+#include "grad_kernel.hpp"
 
 #define SD_TILES(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8)      // feature tiles of 16: one instantiation per count (d <= 128)
 #define SD_TILES_LOGREG(M) M(1) M(2) M(3) M(4)                 // in-loop logistic-regression score: d <= 64 (design matrix in LDS)
@@ -265,6 +266,7 @@ static int prepare_net(const sdeng_desc* d, const Layout& L, float* ws, int DT, 
   pk.w_in = d->net.w_in; pk.b_in = d->net.b_in; pk.w_h1 = d->net.w_h1; pk.b_h1 = d->net.b_h1;
   pk.w_h2 = d->net.w_h2; pk.b_h2 = d->net.b_h2; pk.w_out = d->net.w_out; pk.b_out = d->net.b_out;
   pk.out = ws + L.wpack;
+  pk.transpose = 0; pk.scales = nullptr;
   SD_HIP(sd_launch_pack(pk, s));
   a.wpack = pk.out;
   if (n_times > 0) {
@@ -688,6 +690,66 @@ extern "C" int sdeng_ctrl_forward(const sdeng_desc* d, float t_net, float score_
   SD_HIP(hipMemcpyAsync(dev_coef, host_coef, sizeof(host_coef), hipMemcpyHostToDevice, s));
   a.coef = dev_coef;
   SD_HIP(kCtrlTable[dt_index(DT)][sc](a, grid_for(a.ntiles), s));
+  return 0;
+}
+
+// ---- fused forward + backward of the drift net over N * B rows (training direction) ---------------------------------------------
+#define SD_DECLARE_VJP(DT) int sd_launch_vjp_##DT(const VjpArgs& a, int grid, hipStream_t s);
+SD_TILES(SD_DECLARE_VJP)
+typedef int (*vjp_launch_fn)(const VjpArgs&, int grid, hipStream_t);
+#define SD_TAB_VJP(DT) sd_launch_vjp_##DT,
+static const vjp_launch_fn kVjpTable[8] = {SD_TILES(SD_TAB_VJP)};
+
+static size_t vjp_floats(int DT, int n_times, size_t* o_wt, size_t* o_temb, size_t* o_trash) {
+  size_t o = align64(sd_pack_floats(DT));
+  *o_wt = o; o += align64(sd_lds_weight_floats(DT));
+  *o_temb = o; o += align64(static_cast<size_t>(n_times) * SD_H);
+  *o_trash = o; o += align64(SD_WAVES_MAX * 64 * 4);
+  return o;
+}
+extern "C" size_t sdeng_ctrl_vjp_workspace_bytes(int32_t d, int32_t n_times) {
+  if (d < 1 || d > 128 || n_times < 1) return 0;
+  size_t a, b, c;
+  return vjp_floats(tiles_exact(d), n_times, &a, &b, &c) * sizeof(float);
+}
+extern "C" int sdeng_ctrl_vjp(const sdeng_desc* d, int32_t n_times, int32_t rows_per_time, const float* x, const float* cot, float* a0,
+                              float* a1, float* a2, float* d0, float* d1, float* d2, float* dout, float* gx, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!d || !x || !cot || !a0 || !a1 || !a2 || !d0 || !d1 || !d2 || !dout) return fail(SDENG_E_INVALID, "null argument");
+  if (d->abi_version != SDENG_ABI_VERSION) return fail(SDENG_E_INVALID, "ABI version %d, library has %d", d->abi_version, SDENG_ABI_VERSION);
+  if (d->d < 1 || d->d > 128 || n_times < 1 || rows_per_time < 1 || !d->coef) return fail(SDENG_E_INVALID, "bad sizes (1 <= d <= 128, n_times, rows_per_time >= 1) or null coef");
+  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED) return fail(SDENG_E_UNSUPPORTED, "ctrl_vjp: ClippedCtrl around the FourierMLP (ctrl_kind %d given)", d->net.ctrl_kind);
+  const long long M = static_cast<long long>(n_times) * rows_per_time;
+  if (M * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "rows * d >= 2^31");
+  int rc = check_net(d->net);
+  if (rc) return rc;
+  const int DT = tiles_exact(d->d);
+  size_t o_wt, o_temb, o_trash;
+  const size_t need = vjp_floats(DT, n_times, &o_wt, &o_temb, &o_trash) * sizeof(float);
+  if (!d->workspace || d->workspace_bytes < need) return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, need);
+  float* ws = static_cast<float*>(d->workspace);
+  PackArgs pk;
+  pk.NT = DT; pk.d = d->d;
+  pk.w_in = d->net.w_in; pk.b_in = d->net.b_in; pk.w_h1 = d->net.w_h1; pk.b_h1 = d->net.b_h1;
+  pk.w_h2 = d->net.w_h2; pk.b_h2 = d->net.b_h2; pk.w_out = d->net.w_out; pk.b_out = d->net.b_out;
+  pk.out = ws; pk.transpose = 0; pk.scales = nullptr;
+  SD_HIP(sd_launch_pack(pk, s));
+  PackArgs pt = pk;
+  pt.out = ws + o_wt; pt.transpose = 1; pt.scales = ws + sd_off_scales(DT);
+  SD_HIP(sd_launch_pack(pt, s));
+  TimeEmbedArgs te;
+  te.te = d->net.t_embed; te.coef = d->coef; te.col = 0; te.t_direct = 0; te.t_value = 0.0f; te.clip = 0.0f;
+  te.out = ws + o_temb;
+  SD_HIP(sd_launch_time_embed(te, n_times, s));
+  VjpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = static_cast<int>(M); a.B = rows_per_time; a.d = d->d; a.N = n_times;
+  a.x = x; a.cot = cot; a.wpack = ws; a.wpack_t = ws + o_wt; a.temb = ws + o_temb;
+  a.clip_model = d->net.clip_model;
+  a.a0 = a0; a.a1 = a1; a.a2 = a2; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.dout = dout; a.gx = gx;
+  a.trash = ws + o_trash;
+  a.ntiles = static_cast<int>((M + 15) / 16);
+  SD_HIP(kVjpTable[dt_index(DT)](a, grid_for(a.ntiles), s));
   return 0;
 }
 

@@ -59,6 +59,41 @@ def ctrl_batched(ctrl, t_unique: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return out + (ctrl.sde.diff(t_rows, flat) * score if name == "LerpCtrl" else score)
 
 
+class _FusedIntegral(torch.autograd.Function):
+    """s_b = sum_k <u_theta(t_k, x_kb), zc_kb> for a ClippedCtrl over a FourierMLP, with the gradient w.r.t. the net's parameters from
+    ONE fused HIP forward + backward over all N * B rows (``sdeng_ctrl_vjp``, csrc/grad_kernel.hpp) and six skinny GEMMs -- instead of
+    the ~150 small kernels of the eager torch pass.  The VALUE of s is not needed by the losses (it enters as ``s - s.detach()``), so
+    ``forward`` returns zeros and all the work happens in ``backward``, where the cotangent of s_b (one number per particle) is known."""
+
+    @staticmethod
+    def forward(ctx, ctrl, t_unique, xs, zc, *params):
+        ctx.ctrl, ctx.shape = ctrl, tuple(xs.shape)
+        ctx.save_for_backward(t_unique, xs, zc)
+        return torch.zeros(xs.shape[1], dtype=xs.dtype, device=xs.device)
+
+    @staticmethod
+    def backward(ctx, grad_s):
+        t_unique, xs, zc = ctx.saved_tensors
+        N, B, d = ctx.shape
+        ctrl, net = ctx.ctrl, ctx.ctrl.base_model
+        cot = zc.view(N, B, d) * grad_s.view(1, B, 1)  # d loss / d u_kb
+        r = E.ctrl_vjp(ctrl, t_unique, xs, cot)
+        grads = {net.out_layer.weight: r["dout"].t() @ r["a2"], net.out_layer.bias: r["dout"].sum(0),
+                 net.hidden_layer[1].weight: r["d2"].t() @ r["a1"], net.hidden_layer[1].bias: r["d2"].sum(0),
+                 net.hidden_layer[0].weight: r["d1"].t() @ r["a0"], net.hidden_layer[0].bias: r["d1"].sum(0),
+                 net.input_embed.weight: r["d0"].t() @ r["x"], net.input_embed.bias: r["d0"].sum(0)}
+        # time embedding e_t = timestep_embed(t_k): its cotangent is the sum over the particles of d0; the small module itself (2 layers on
+        # N rows) is differentiated by torch
+        te_params = [p for p in net.timestep_embed.parameters() if p.requires_grad]
+        if te_params:
+            with torch.enable_grad():
+                e = net.timestep_embed(t_unique.view(-1, 1))
+                te_grads = torch.autograd.grad(e, te_params, grad_outputs=r["d0"].view(N, B, 64).sum(1), allow_unused=True)
+            grads.update({p: g for p, g in zip(te_params, te_grads) if g is not None})
+        params = [p for p in ctrl.parameters() if p.requires_grad]
+        return (None, None, None, None) + tuple(grads.get(p) for p in params)
+
+
 class _IntegralPass(torch.nn.Module):
     """s_b = sum_k <u(t_k, x_kb), zc_kb>: the one part of the log-variance loss that carries a graph (BaseOCLoss._lv_loss)."""
 
@@ -104,6 +139,7 @@ class BaseOCLoss:
         self._coef_cache = {}
         self._cpu_sde = None
         self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
+        self.fused_training = True  # ClippedCtrl over a FourierMLP: the batched control pass of training as ONE fused HIP forward + backward (sdeng_ctrl_vjp); False: the eager torch pass
         self.graph_training = False  # True: the batched control pass of log-variance training (forward + backward) is replayed as a hipGraph (_IntegralPass)
         self._graphed = {}
         self.split_tiles = False  # True: small batches (<= _lib.SPLIT_TILES_MAX_B = 8 192, the library's own gate) ask for the low-latency kernels (SDENG_FLAG_SPLIT_TILES; fp32-round-off, not bit, equal to the standard kernel); the solvers switch it on (cfg 'split_tiles', default True)
@@ -223,6 +259,10 @@ class BaseOCLoss:
         # RemoveReferenceCtrl: u = inner - ref_score and ref_score has no parameters, so s - s.detach() of the inner control carries the
         # same (zero) value and the same gradient
         ctrl = E.unwrap_ctrl(self.generative_ctrl)[0] if type(self.generative_ctrl).__name__ == "RemoveReferenceCtrl" else self.generative_ctrl
+        if self.fused_training and type(ctrl).__name__ == "ClippedCtrl" and type(getattr(ctrl, "base_model", None)).__name__ == "FourierMLP":
+            # the drift net of every RDS / LRDS solver (conf/model/basic.yaml): fused HIP forward + backward (csrc/grad_kernel.hpp)
+            params = [p for p in ctrl.parameters() if p.requires_grad]
+            return _FusedIntegral.apply(ctrl, t_unique, xs.contiguous(), zc.view(xs.shape), *params)
         key = (id(ctrl), tuple(xs.shape), str(xs.device))
         fn = self._graphed.get(key)
         if fn is None:
@@ -599,8 +639,8 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
             raise E.UnsupportedByEngine("CMCD: initial_log_prob must be the log-density of sde.prior_score's distribution")
         desc.target = E.dist_desc(target, device, keep, clip=res[1])
         desc.prior = E.dist_desc(prior, device, keep)
-        desc.cmcd_g = float(self.sde.diff_coeff)
-        desc.cmcd_clip = float(self.sde.clip_score) if self.sde.clip_score else 0.0
+        desc.cmcd_g = E.scalar_of(self.sde.diff_coeff)
+        desc.cmcd_clip = E.scalar_of(self.sde.clip_score) if self.sde.clip_score else 0.0
         coef = self._coef(ts, device, kind="cmcd_eubo") if eubo else self._coef(ts, device)
         keep.append(coef)
         desc.coef = coef.data_ptr()

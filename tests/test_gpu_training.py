@@ -119,3 +119,42 @@ def test_ema_weights_are_used_for_evaluation(gpu):
     a = model.evaluate(use_ema=True).metrics["eval/elbo"]
     b = model.evaluate(use_ema=False).metrics["eval/elbo"]
     assert a != b  # the EMA copy and the live net drive different samplers
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,N,B,clip", [(128, 7, 37, 1e4), (100, 5, 64, 0.05), (16, 9, 20, None), (2, 3, 5, 1e4), (61, 4, 48, 0.2)])
+def test_fused_forward_backward_of_the_drift_net_matches_autograd(gpu, d, N, B, clip):
+    """sdeng_ctrl_vjp (csrc/grad_kernel.hpp): per-row activations / cotangents of the drift net, the six parameter-gradient products built
+    from them and the state gradient, against torch autograd of the same ClippedCtrl in fp64.  Rows per time not a multiple of the
+    16-row tile, an ACTIVE clip (its mask must gate the cotangent exactly like torch.clip's backward), small cotangents (1e-6)."""
+    import copy
+
+    from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
+    from sde_sampler_lrds_amd.models.reparam import ClippedCtrl
+    torch.manual_seed(d + N)
+    ctrl = ClippedCtrl(base_model=cfgs._net(d), clip_model=clip).to(gpu)
+    ts = torch.linspace(0.05, 0.9, N, device=gpu)
+    xs = 1.5 * torch.randn(N, B, d, device=gpu)
+    cot = 1e-6 * torch.randn(N, B, d, device=gpu) * (1.0 + 10.0 * torch.rand(N, B, 1, device=gpu))
+    r = E.ctrl_vjp(ctrl, ts, xs, cot, want_gx=True)
+    net = ctrl.base_model
+    got = {"out_layer.weight": r["dout"].t() @ r["a2"], "out_layer.bias": r["dout"].sum(0), "hidden_layer.1.weight": r["d2"].t() @ r["a1"],
+           "hidden_layer.1.bias": r["d2"].sum(0), "hidden_layer.0.weight": r["d1"].t() @ r["a0"], "hidden_layer.0.bias": r["d1"].sum(0),
+           "input_embed.weight": r["d0"].t() @ r["x"], "input_embed.bias": r["d0"].sum(0)}
+    # fp64 autograd of the same module
+    c64 = copy.deepcopy(ctrl).double()
+    x64 = xs.double().requires_grad_(True)
+    u = torch.stack([c64(ts[k].double(), x64[k]) for k in range(N)])
+    (u * cot.double()).sum().backward()
+    worst = 0.0
+    for k, v in got.items():
+        ref = dict(c64.base_model.named_parameters())[k].grad
+        err = float((v.double() - ref).abs().max() / ref.abs().max().clamp(min=1e-30))
+        worst = max(worst, err)
+        assert err < 2e-5, (k, err)
+    egx = float((r["gx"].view(N, B, d).double() - x64.grad).abs().max() / x64.grad.abs().max())
+    n_clipped = int((u.detach().abs() > clip).sum()) if clip else 0
+    print(f"ctrl_vjp d={d} N={N} B={B} clip={clip}: worst parameter-gradient error {worst:.2e}, state gradient {egx:.2e} (vs fp64 autograd; {n_clipped} clipped outputs)")
+    assert egx < 2e-5
+    if clip is not None and clip < 1.0:
+        assert n_clipped > 0

@@ -16,14 +16,19 @@ for d, B, N in ((16, 512, 100), (128, 512, 100), (128, 2048, 256)):
                        dict(means_ref=4 * torch.rand(4, d, generator=g) - 2, variances_ref=0.5 * torch.ones(4, d), weights_ref=torch.ones(4)),
                        tgt, dict(train_steps=10, train_batch_size=B, eval_batch_size=B), optim_details=dict(lr=1e-3), n_steps=N)
     model.setup_optim()
-    for i in range(5):
-        model.step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(20):
-        model.step(i)
-    torch.cuda.synchronize()
-    per = (time.perf_counter() - t0) / 20
+    per_mode = {}
+    for fused in (False, True):  # the batched control pass as eager torch autograd, then as the fused HIP forward + backward
+        model.loss.fused_training = fused
+        for i in range(5):
+            model.step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(20):
+            model.step(i)
+        torch.cuda.synchronize()
+        per_mode[fused] = (time.perf_counter() - t0) / 20
+    per = per_mode[True]
+    print(f"d={d} B={B} N={N}: training step {per_mode[False]*1e3:.2f} ms with the eager batched pass, {per_mode[True]*1e3:.2f} ms with sdeng_ctrl_vjp", flush=True)
     x = model.prior.sample((B,)).to(model.device)
     ts = model.train_ts
     torch.cuda.synchronize(); t0 = time.perf_counter()
