@@ -182,7 +182,10 @@ class TrainableDiff:
 
     def setup_optim(self):
         o = dict(self.cfg.get("optim") or {})
-        self.optim = torch.optim.Adam(self.trainable_parameters(), **{"lr": 3e-4, **o})  # conf/solver/basic_oc_base.yaml:19-21
+        params = self.trainable_parameters()
+        if "fused" not in o and "foreach" not in o and params and all(p.is_cuda for p in params):
+            o["fused"] = True  # one kernel for the whole update (same arithmetic as the default foreach implementation)
+        self.optim = torch.optim.Adam(params, **{"lr": 3e-4, **o})  # conf/solver/basic_oc_base.yaml:19-21
         self.train_steps = self.cfg.get("train_steps", 0)
         self.max_loss, self.max_grad, self.scale_loss = self.cfg.get("max_loss"), self.cfg.get("max_grad"), self.cfg.get("scale_loss")
         self.grad_clip_norm = self.cfg.get("grad_clip_norm")
@@ -214,7 +217,7 @@ class TrainableDiff:
         # one read-back for all parameters (a per-parameter bool() costs a stream synchronisation each): max |grad| is NaN / inf
         # exactly when some gradient entry is (solver/base.py:425-433 checks every parameter)
         grads = [p.grad for p in params if p.grad is not None]
-        mg = float(torch.stack([g.abs().max() for g in grads]).max()) if grads else 0.0
+        mg = float(torch.stack(torch._foreach_norm(grads, float("inf"))).max()) if grads else 0.0  # (two kernels, not two per parameter)
         if self.max_grad is None:
             grad_ok = math.isfinite(mg)
         else:
