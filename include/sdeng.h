@@ -285,6 +285,20 @@ int sdeng_ctrl_vjp(const sdeng_desc* desc, int32_t n_times, int32_t rows_per_tim
                    float* a2, float* d0, float* d1, float* d2, float* dout, float* gx, void* stream);
 size_t sdeng_ctrl_vjp_workspace_bytes(int32_t d, int32_t n_times);
 
+/* Annealed samplers: n_moves Langevin moves of B chains in ONE launch -- mala_step / ula_step of additions/mcmc.py:77-135,
+ * 189-221 with the per-chain step-size heuristic of :55-74 (target_acceptance > 0), as smc_sampler / re_sampler / mcmc_sample apply
+ * them move after move (additions/ebm_mle.py:120-160, 340-380; experiments/benchmark_utils.py:300-330).  Density: the geometric path
+ * log pi_t = (1 - t[b]) log p_prior + t[b] log pi~ (prior == NULL or kind NONE: the target alone; t == NULL: 1).  State in / out:
+ * x [B,d], lp [B] = log pi_t(x), grad [B,d], step [B].  Noise: injected normals z [n_moves,B,d] and uniforms u [n_moves,B] (u unused
+ * by the unadjusted move) -- e.g. drawn from the host framework's generator in the reference's order -- or NULL: Philox streams 2 / 3
+ * keyed by (seed, chain0 + chain, move).  samples (optional) [n_moves - keep_from, B, d]: the states after moves keep_from..;
+ * acc_sum (optional) [B]: sum over those moves of min(1, acceptance ratio); acc_last (optional) [B]: that of the last move. */
+int sdeng_langevin_moves(const sdeng_dist* prior, const sdeng_dist* target, int32_t B, int32_t d, int32_t n_moves, int32_t keep_from,
+                         int32_t unadjusted, float target_acceptance, const float* t, float* x, float* lp, float* grad, float* step,
+                         const float* z, const float* u, uint64_t seed, int64_t chain0, float* samples, float* acc_sum, float* acc_last,
+                         void* workspace, size_t workspace_bytes, void* stream);
+size_t sdeng_langevin_moves_workspace_bytes(const sdeng_dist* prior, const sdeng_dist* target, int32_t d);
+
 /* prior.sample((B,)) on the device, out[B,d]: exactly the x0 that sdeng_simulate draws for x_in == NULL with the same
  * (dist, seed, particle0).  Replaces IsotropicGauss.sample / Gauss.sample / Delta.sample / GaussFull.sample (distr/gauss.py:772-787,
  * 235-239, 709-713; distr/delta.py:27-31). */

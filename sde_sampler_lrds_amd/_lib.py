@@ -66,7 +66,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsdeng.so
 
 EXPORTS = ["sdeng_abi_version", "sdeng_last_error", "sdeng_workspace_bytes", "sdeng_simulate", "sdeng_logz",
            "sdeng_logz_workspace_bytes", "sdeng_ctrl_forward", "sdeng_dist_eval", "sdeng_dist_workspace_bytes",
-           "sdeng_philox_normal", "sdeng_philox_normal_steps", "sdeng_sample_x0", "sdeng_ctrl_vjp", "sdeng_ctrl_vjp_workspace_bytes"]
+           "sdeng_philox_normal", "sdeng_philox_normal_steps", "sdeng_sample_x0", "sdeng_ctrl_vjp", "sdeng_ctrl_vjp_workspace_bytes",
+           "sdeng_langevin_moves", "sdeng_langevin_moves_workspace_bytes"]
 
 
 def lib() -> C.CDLL:
@@ -105,6 +106,11 @@ def lib() -> C.CDLL:
     L.sdeng_ctrl_vjp.argtypes = [C.POINTER(Desc), C.c_int32, C.c_int32] + [C.c_void_p] * 11
     L.sdeng_ctrl_vjp_workspace_bytes.restype = C.c_size_t
     L.sdeng_ctrl_vjp_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.sdeng_langevin_moves.restype = C.c_int
+    L.sdeng_langevin_moves.argtypes = [C.POINTER(Dist), C.POINTER(Dist), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float] + \
+        [C.c_void_p] * 7 + [C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.sdeng_langevin_moves_workspace_bytes.restype = C.c_size_t
+    L.sdeng_langevin_moves_workspace_bytes.argtypes = [C.POINTER(Dist), C.POINTER(Dist), C.c_int32]
     if L.sdeng_abi_version() != ABI_VERSION:
         raise ImportError(f"libsdeng.so ABI {L.sdeng_abi_version()} != binding ABI {ABI_VERSION}")
     _LIB = L

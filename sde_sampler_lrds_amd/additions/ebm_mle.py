@@ -22,7 +22,31 @@ def hip_tempered_log_prob_and_grads(target, prior):
         lp0, s0 = E.dist_eval(prior, x.detach())
         w = t.to(x.dtype).expand(x.shape[0], 1) if t.dim() else t
         return ((1.0 - w) * lp0 + w * lp1).flatten(), (1.0 - w) * s0 + w * s1
+    fn.hip_pair = (target, prior)  # lets the samplers below run whole levels of local moves in one launch (sdeng_langevin_moves)
     return fn
+
+
+# Local moves of a level as ONE HIP launch (csrc/prep_kernels.hip k_langevin_moves) when the annealing path is
+# hip_tempered_log_prob_and_grads and the moves are not preconditioned.  NATIVE_NOISE = False: the random numbers still come from torch's
+# generator, drawn in the reference's order (the chains are then the reference's chains, tests/golden/smc_*.npz, re_*.npz);
+# True: counter-based draws inside the kernel (seeded by NATIVE_SEED and a per-call counter).
+NATIVE_MOVES, NATIVE_NOISE, NATIVE_SEED = True, False, 1
+_native_calls = [0]
+
+
+def _native_pair(log_prob_and_grads, x, precond):
+    pair = getattr(log_prob_and_grads, "hip_pair", None)
+    if not NATIVE_MOVES or pair is None or precond is not None or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32:
+        return None
+    return pair
+
+
+def _native_run(pair, t, x, lp, grad, step, n_moves, keep_from, use_ula, target_acceptance, want_samples=True):
+    """n_moves local moves of all chains; x / lp / grad / step ([B,d], [B], [B,d], [B] contiguous) are updated in place."""
+    _native_calls[0] += 1
+    return E.langevin_moves(pair[0], pair[1], x, lp, grad, step, n_moves, t=t, keep_from=keep_from, unadjusted=use_ula,
+                            target_acceptance=target_acceptance if not use_ula else 0.0, noise="philox" if NATIVE_NOISE else "torch",
+                            seed=(NATIVE_SEED + 0x9E3779B97F4A7C15 * _native_calls[0]) & 0xFFFFFFFFFFFFFFFF, want_samples=want_samples)
 
 
 def _pmul(mat, v):
@@ -107,14 +131,23 @@ def smc_sampler(x_init, times, log_prob_and_grads, n_warmup_mcmc_steps, n_mcmc_s
                 if use_precond:
                     pgrad = pgrad[idx]
                 log_w.zero_()
-        for _ in range(n_warmup_mcmc_steps):
-            x, lp, grad, pgrad, step, _ = move(x, lp, grad, pgrad, step)
-        acc_sum = 0.0
-        for i in range(n_mcmc_steps):
-            x, lp, grad, pgrad, step, log_acc = move(x, lp, grad, pgrad, step)
-            if log_acc is not None:
-                acc_sum = acc_sum + torch.exp(torch.minimum(torch.zeros_like(log_acc), log_acc))
-            samples[lvl, i] = x.clone()
+        pair = _native_pair(log_prob_and_grads, x, precond)
+        if pair is not None:  # all warm-up and sampling moves of the level in one launch
+            x, lp, grad = x.contiguous(), lp.contiguous().clone(), grad.contiguous().clone()
+            step_flat = step.to(torch.float32).reshape(-1).expand(B).contiguous().clone()
+            got, acc_sum, _ = _native_run(pair, times[lvl].reshape(-1), x, lp, grad, step_flat, n_warmup_mcmc_steps + n_mcmc_steps,
+                                          n_warmup_mcmc_steps, use_ula, target_acceptance)
+            samples[lvl] = got
+            step = step_flat.view(step.shape)
+        else:
+            for _ in range(n_warmup_mcmc_steps):
+                x, lp, grad, pgrad, step, _ = move(x, lp, grad, pgrad, step)
+            acc_sum = 0.0
+            for i in range(n_mcmc_steps):
+                x, lp, grad, pgrad, step, log_acc = move(x, lp, grad, pgrad, step)
+                if log_acc is not None:
+                    acc_sum = acc_sum + torch.exp(torch.minimum(torch.zeros_like(log_acc), log_acc))
+                samples[lvl, i] = x.clone()
         if not use_ula:
             mean_accs[lvl] = (acc_sum / n_mcmc_steps).mean()
         step_sizes_per_noise[lvl] = step.clone()
@@ -188,7 +221,34 @@ def re_sampler(x_init, times, log_prob_and_grads, swap_frequency, n_warmup_mcmc_
     lp, grad = move.f(x)
     pgrad = move.pgrad(grad)
     pairs = make_re_pairings(n_levels, x_init.device)
-    for it in range(n_warmup_mcmc_steps + n_mcmc_steps):
+    native = _native_pair(log_prob_and_grads, x, precond)
+    total = n_warmup_mcmc_steps + n_mcmc_steps
+    if native is not None:
+        x, lp, grad = x.contiguous().clone(), lp.contiguous().clone(), grad.contiguous().clone()
+        step_shape, step = step.shape, step.to(torch.float32).reshape(-1).expand(x.shape[0]).contiguous().clone()
+    it = 0
+    while native is not None and it < total:
+        if it % swap_frequency == 0:
+            pr = pairs[(it // swap_frequency) % 2]
+            xs_, lps_, gs_, mean_swap_acc = re_step(x.view((-1, B, *data_shape)), lp.view((-1, B)), grad.view((-1, B, *data_shape)), batched,
+                                                    times, pr[:, 0], pr[:, 1], B, data_shape, ones)
+            x, grad, lp = xs_.reshape((-1, *data_shape)).contiguous(), gs_.reshape((-1, *data_shape)).contiguous(), lps_.flatten().contiguous()
+            if it >= n_warmup_mcmc_steps:
+                samples[:, it - n_warmup_mcmc_steps] = x.reshape((-1, B, *data_shape))
+            it += 1
+            continue
+        run = min(swap_frequency - it % swap_frequency, total - it) if swap_frequency > 0 else total - it  # local moves up to the next swap step
+        keep = max(0, n_warmup_mcmc_steps - it)
+        got, _, last = _native_run(native, t_flat.reshape(-1), x, lp, grad, step, run, min(keep, run), use_ula, target_acceptance, want_samples=keep < run)
+        if keep < run:
+            first = it + keep - n_warmup_mcmc_steps
+            samples[:, first:first + run - keep] = got.view(run - keep, n_levels, B, *data_shape).transpose(0, 1)
+        if last is not None:
+            mean_local_accs = last.view((-1, B)).mean(dim=-1)
+        it += run
+    if native is not None:
+        step = step.view(step_shape)
+    for it in range(0 if native is None else total, total):
         if it % swap_frequency == 0:
             pr = pairs[(it // swap_frequency) % 2]
             x, lp, grad, mean_swap_acc = re_step(x.view((-1, B, *data_shape)), lp.view((-1, B)), grad.view((-1, B, *data_shape)), batched,

@@ -16,6 +16,7 @@ def hip_log_prob_and_grad(target):
     def fn(y):
         logp, score = E.dist_eval(target, y.detach())
         return logp.flatten(), score
+    fn.hip_target = target  # lets mcmc_sample run all its MALA steps in one launch (sdeng_langevin_moves)
     return fn
 
 

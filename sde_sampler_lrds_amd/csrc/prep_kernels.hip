@@ -736,6 +736,111 @@ __global__ void __launch_bounds__(SD_EVAL_THREADS) k_dist_eval(DistEvalArgs a) {
   if (a.score_out && writer) dist_score_row(a, x, a.score_out + static_cast<size_t>(row) * a.d);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Langevin moves of the annealed samplers: one thread per chain, the chain's state / gradient / proposal rows in LDS, all K
+// moves of a level in ONE launch -- the reference (and the host composition this replaces) spends ~30 small launches per move.
+// ------------------------------------------------------------------------------------------------
+#define SD_MOVE_ROWS 5  // x, grad, proposal, gradient at the proposal, scratch score row
+__device__ inline void tempered_eval(const MovesArgs& a, float w, const float* y, float* g_out, float* tmp, float& lp_out) {
+  const bool both = a.prior.ds.kind != SDENG_DIST_NONE;
+  const float lp1 = dist_logp_row(a.target, y);
+  dist_score_row(a.target, y, g_out);
+  if (!both) {
+    lp_out = lp1;
+    return;
+  }
+  const float lp0 = dist_logp_row(a.prior, y);
+  dist_score_row(a.prior, y, tmp);
+  lp_out = (1.0f - w) * lp0 + w * lp1;   // ebm_mle.py's tempered density (hip_tempered_log_prob_and_grads)
+  for (int f = 0; f < a.d; ++f) g_out[f] = (1.0f - w) * tmp[f] + w * g_out[f];
+}
+
+__global__ void __launch_bounds__(64) k_langevin_moves(MovesArgs a, int chains_per_block) {
+  extern __shared__ float sh[];
+  const int tid = threadIdx.x, d = a.d, stride = d | 1;
+  const int chain = blockIdx.x * chains_per_block + tid;
+  if (tid >= chains_per_block || chain >= a.B) return;  // (no barriers below: a chain is one thread)
+  float* xr = sh + (tid * SD_MOVE_ROWS + 0) * stride;
+  float* gr = xr + stride;
+  float* pr = gr + stride;
+  float* gp = pr + stride;
+  float* tmp = gp + stride;
+  for (int f = 0; f < d; ++f) {
+    xr[f] = a.x[static_cast<size_t>(chain) * d + f];
+    gr[f] = a.grad[static_cast<size_t>(chain) * d + f];
+  }
+  float lp = a.lp[chain], step = a.step[chain], acc = 0.0f, last = 1.0f;
+  const float w = a.t ? a.t[chain] : 1.0f;
+  const uint32_t cidx = static_cast<uint32_t>(a.chain0 + chain);
+  const float log_target = a.target_acc > 0.0f ? logf(a.target_acc) : 0.0f;
+  for (int m = 0; m < a.K; ++m) {
+    const float sd = sqrtf(2.0f * step);
+    // proposal: sample_multivariate_normal_diag(mean = y + h grad, variance = 2 h)  (mcmc.py:19-21, :97-99)
+    for (int f0 = 0; f0 < d; f0 += 4) {
+      f32x4 z;
+      if (a.z) {
+        for (int r = 0; r < 4; ++r) z[r] = f0 + r < d ? a.z[(static_cast<size_t>(m) * a.B + chain) * d + f0 + r] : 0.0f;
+      } else {
+        z = philox_normal4(cidx, static_cast<uint32_t>(m), static_cast<uint32_t>(f0 >> 2), 2u, a.seed_lo, a.seed_hi);
+      }
+      for (int r = 0; r < 4 && f0 + r < d; ++r) pr[f0 + r] = sd * z[r] + (xr[f0 + r] + step * gr[f0 + r]);
+    }
+    float lp_p;
+    tempered_eval(a, w, pr, gp, tmp, lp_p);
+    bool accept = true;
+    float log_acc = 0.0f;
+    if (!a.ula) {
+      // log q(prop | y) and log q(y | prop), unnormalised: -0.5 sum (samples - mean)^2 / variance  (mcmc.py:24-31)
+      float qf = 0.0f, qb = 0.0f;
+      for (int f = 0; f < d; ++f) {
+        const float df = pr[f] - (xr[f] + step * gr[f]);
+        const float db = xr[f] - (pr[f] + step * gp[f]);
+        qf += df * df;
+        qb += db * db;
+      }
+      const float var = 2.0f * step;
+      const float joint_prop = lp_p - (-0.5f * qf) / var, joint_orig = lp - (-0.5f * qb) / var;
+      log_acc = joint_prop - joint_orig;
+      float uu;
+      if (a.u) {
+        uu = a.u[static_cast<size_t>(m) * a.B + chain];
+      } else {
+        uint32_t r4[4];
+        philox4x32_10(cidx, 0u, static_cast<uint32_t>(m), 3u, a.seed_lo, a.seed_hi, r4);
+        uu = u01(r4[0]);
+      }
+      accept = logf(uu) < log_acc;
+    }
+    if (accept) {
+      for (int f = 0; f < d; ++f) {
+        xr[f] = pr[f];
+        gr[f] = gp[f];
+      }
+      lp = lp_p;
+    }
+    if (!a.ula && a.target_acc > 0.0f) {  // heuristics_step_size (mcmc.py:55-74), per chain
+      if (log_acc - log_target > 0.04879016416943205f) step = step * 1.01f;        // log1p(0.05)
+      if (log_target - log_acc > 0.05129329438755058f) step = step / 1.01f;        // -log1p(-0.05)
+    }
+    if (!a.ula) last = expf(fminf(0.0f, log_acc));
+    if (m >= a.keep_from) {
+      if (!a.ula) acc += last;
+      if (a.samples) {
+        float* dst = a.samples + (static_cast<size_t>(m - a.keep_from) * a.B + chain) * d;
+        for (int f = 0; f < d; ++f) dst[f] = xr[f];
+      }
+    }
+  }
+  for (int f = 0; f < d; ++f) {
+    a.x[static_cast<size_t>(chain) * d + f] = xr[f];
+    a.grad[static_cast<size_t>(chain) * d + f] = gr[f];
+  }
+  a.lp[chain] = lp;
+  a.step[chain] = step;
+  if (a.acc_sum) a.acc_sum[chain] = acc;
+  if (a.acc_last) a.acc_last[chain] = last;
+}
+
 // terminal cost, in place on rnd (losses/oc.py:290: rnd += ref_logp(x) - target_logp(x); :973: rnd -= target_logp(x))
 __global__ void __launch_bounds__(SD_EVAL_THREADS) k_terminal(TerminalArgs a) {
   extern __shared__ float sh[];
@@ -949,6 +1054,16 @@ int sd_launch_dist_tables(const DistTabArgs& a, hipStream_t s) {
 }
 int sd_launch_dist_eval(const DistEvalArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_dist_eval, dim3((a.B + SD_EVAL_ROWS - 1) / SD_EVAL_ROWS), dim3(SD_EVAL_THREADS), (SD_EVAL_ROWS * (a.d | 1) + SD_EVAL_RED_FLOATS) * sizeof(float), s, a);
+  return static_cast<int>(hipGetLastError());
+}
+int sd_launch_moves(const MovesArgs& a, hipStream_t s) {
+  const int stride = a.d | 1;
+  int cpb = 64;
+  while (cpb > 8 && static_cast<size_t>(cpb) * SD_MOVE_ROWS * stride * sizeof(float) > 150 * 1024) cpb /= 2;  // d > ~115: 32 chains per block
+  const size_t lds = static_cast<size_t>(cpb) * SD_MOVE_ROWS * stride * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_langevin_moves), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL(k_langevin_moves, dim3((a.B + cpb - 1) / cpb), dim3(64), lds, s, a, cpb);
   return static_cast<int>(hipGetLastError());
 }
 int sd_launch_terminal(const TerminalArgs& a, hipStream_t s) {

@@ -73,6 +73,24 @@ struct DistEvalArgs {
   float* score_out;
 };
 
+// K Langevin moves (MALA or ULA) of B chains at fixed tempering weights, state in LDS: additions/mcmc.py:77-135 (mala_step), :189-221
+// (ula_step) with the step-size heuristic of :55-74, on the geometric path log pi_t = (1 - t) log p_prior + t log pi~ (ebm_mle.py's
+// tempered densities; prior.ds.kind == NONE: the target alone, e.g. the MALA chains of experiments/benchmark_utils.py:268-333)
+struct MovesArgs {
+  DistEvalArgs prior, target;   // .ds / .d / .dpad of the two ends of the path
+  int B, d, K, keep_from, ula;  // chains, dimension, moves, first stored move, 1 = unadjusted
+  float target_acc;             // <= 0: step sizes stay fixed
+  const float* t;               // [B] tempering weight of each chain, or nullptr (1)
+  float *x, *lp, *grad, *step;  // [B,d], [B], [B,d], [B]: chain state, carried in and out
+  const float *z, *u;           // injected normals [K,B,d] and uniforms [K,B] (MALA), or nullptr: counter-based Philox draws
+  unsigned seed_lo, seed_hi;
+  long long chain0;             // global index of chain 0 (Philox counter)
+  float* samples;               // [K - keep_from, B, d] states after each stored move, or nullptr
+  float* acc_sum;               // [B] sum over the stored moves of min(1, acceptance ratio), or nullptr
+  float* acc_last;              // [B] min(1, acceptance ratio) of the last move, or nullptr
+};
+int sd_launch_moves(const MovesArgs& a, hipStream_t s);
+
 struct TerminalArgs {
   DistDev ref, target;
   int use_ref, use_target;

@@ -771,6 +771,44 @@ extern "C" int sdeng_dist_eval(const sdeng_dist* dist, int32_t B, int32_t d, con
   return 0;
 }
 
+// ---- Langevin moves of the annealed samplers ------------------------------------------------------------------------
+extern "C" size_t sdeng_langevin_moves_workspace_bytes(const sdeng_dist* prior, const sdeng_dist* target, int32_t d) {
+  if (!target || d < 1) return 0;
+  const int dpad = 16 * ((d + 15) / 16);
+  return (dist_floats(*target, dpad) + (prior ? dist_floats(*prior, dpad) : 0) + 64) * sizeof(float);
+}
+extern "C" int sdeng_langevin_moves(const sdeng_dist* prior, const sdeng_dist* target, int32_t B, int32_t d, int32_t n_moves, int32_t keep_from,
+                                    int32_t unadjusted, float target_acceptance, const float* t, float* x, float* lp, float* grad, float* step,
+                                    const float* z, const float* u, uint64_t seed, int64_t chain0, float* samples, float* acc_sum,
+                                    float* acc_last, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!target || !x || !lp || !grad || !step || B < 0 || d < 1 || n_moves < 0 || keep_from < 0) return fail(SDENG_E_INVALID, "bad argument");
+  if (d > 255) return fail(SDENG_E_UNSUPPORTED, "langevin_moves: d <= 255 (chain rows live in LDS), got %d", d);
+  if ((z == nullptr) != (u == nullptr) && !unadjusted) return fail(SDENG_E_INVALID, "MALA: inject both the normals and the uniforms, or neither");
+  if (B == 0 || n_moves == 0) return 0;
+  const int dpad = 16 * ((d + 15) / 16);
+  const size_t need = sdeng_langevin_moves_workspace_bytes(prior, target, d);
+  if (!workspace || workspace_bytes < need) return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", workspace_bytes, need);
+  float* ws = static_cast<float*>(workspace);
+  MovesArgs a;
+  memset(&a, 0, sizeof(a));
+  int rc = build_dist(*target, d, dpad, ws, a.target.ds, s);
+  if (rc) return rc;
+  a.target.d = d; a.target.dpad = dpad; a.target.B = B;
+  a.prior.ds.kind = SDENG_DIST_NONE;
+  if (prior && prior->kind != SDENG_DIST_NONE) {
+    rc = build_dist(*prior, d, dpad, ws + dist_floats(*target, dpad), a.prior.ds, s);
+    if (rc) return rc;
+  }
+  a.prior.d = d; a.prior.dpad = dpad; a.prior.B = B;
+  a.B = B; a.d = d; a.K = n_moves; a.keep_from = keep_from; a.ula = unadjusted ? 1 : 0; a.target_acc = target_acceptance;
+  a.t = t; a.x = x; a.lp = lp; a.grad = grad; a.step = step; a.z = z; a.u = u;
+  a.seed_lo = static_cast<unsigned>(seed & 0xFFFFFFFFull); a.seed_hi = static_cast<unsigned>(seed >> 32); a.chain0 = chain0;
+  a.samples = samples; a.acc_sum = acc_sum; a.acc_last = acc_last;
+  SD_HIP(sd_launch_moves(a, s));
+  return 0;
+}
+
 extern "C" size_t sdeng_dist_workspace_bytes(const sdeng_dist* dist, int32_t d) {
   if (!dist || d < 1) return 0;
   return dist_floats(*dist, 16 * ((d + 15) / 16)) * sizeof(float);

@@ -671,6 +671,44 @@ def dist_eval(dist, x: torch.Tensor, want_logp=True, want_score=True):
     return logp, score
 
 
+def langevin_moves(target, prior, x, lp, grad, step, n_moves, *, t=None, keep_from=0, unadjusted=False, target_acceptance=0.0, noise="torch",
+                   seed=0, chain0=0, want_samples=True):
+    """sdeng_langevin_moves: ``n_moves`` MALA / ULA moves of all chains in one launch (include/sdeng.h).  ``x`` [B,d], ``lp`` [B], ``grad``
+    [B,d], ``step`` [B] are updated IN PLACE.  ``noise='torch'``: the normals (and uniforms) are drawn from torch's generator move by move in
+    the order additions/mcmc.py consumes them (randn((B,d)) then rand_like(lp)), so a chain is the one the reference's loop produces;
+    ``noise='philox'``: drawn in the kernel.  Returns (samples [n_moves - keep_from, B, d] or None, acc_sum [B] or None, acc_last [B] or None)."""
+    require_gpu(x)
+    lib = L.lib()
+    device, keep = x.device, []
+    B, d = x.shape
+    for name, v in (("x", x), ("lp", lp), ("grad", grad), ("step", step)):
+        if v.dtype != torch.float32 or not v.is_contiguous() or not v.is_cuda:
+            raise ValueError(f"langevin_moves: {name} must be a contiguous float32 CUDA tensor (it is updated in place)")
+    dt = dist_desc(target, device, keep)
+    dp = dist_desc(prior, device, keep) if prior is not None else None
+    z = u = None
+    if noise == "torch":
+        z = torch.empty(n_moves, B, d, dtype=torch.float32, device=device)
+        u = torch.empty(n_moves, B, dtype=torch.float32, device=device) if not unadjusted else None
+        for m in range(n_moves):  # the reference's consumption order: one randn per proposal, then one rand per accept test
+            z[m] = torch.randn((B, d), device=device)
+            if u is not None:
+                u[m] = torch.rand((B,), device=device)
+    elif noise != "philox":
+        raise ValueError("noise: 'torch' or 'philox'")
+    tt = None if t is None else t.detach().to(device=device, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+    samples = torch.empty(n_moves - keep_from, B, d, dtype=torch.float32, device=device) if want_samples else None
+    acc = torch.empty(B, dtype=torch.float32, device=device) if not unadjusted else None
+    last = torch.empty(B, dtype=torch.float32, device=device) if not unadjusted else None
+    need = lib.sdeng_langevin_moves_workspace_bytes(C.byref(dp) if dp is not None else None, C.byref(dt), d)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+    ptr = lambda v: None if v is None else v.data_ptr()  # noqa: E731
+    L.check(lib.sdeng_langevin_moves(C.byref(dp) if dp is not None else None, C.byref(dt), B, d, int(n_moves), int(keep_from), int(bool(unadjusted)),
+                                     float(target_acceptance), ptr(tt), x.data_ptr(), lp.data_ptr(), grad.data_ptr(), step.data_ptr(), ptr(z), ptr(u),
+                                     int(seed), int(chain0), ptr(samples), ptr(acc), ptr(last), ws.data_ptr(), ws.numel(), _stream_ptr(device)))
+    return samples, acc, last
+
+
 def ctrl_vjp(ctrl, t_unique: torch.Tensor, xs: torch.Tensor, cot: torch.Tensor, want_gx=False):
     """sdeng_ctrl_vjp: fused forward + backward of a ClippedCtrl / FourierMLP over all (time, state) rows.  ``xs`` and ``cot`` are
     [N, B, d] (states at the N times ``t_unique`` and the cotangent of the control there).  Returns the per-row arrays the parameter

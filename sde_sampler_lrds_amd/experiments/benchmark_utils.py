@@ -259,6 +259,15 @@ def mcmc_sample(device, target, x_init, mcmc_type="mala", step_size=1e-3, n_chai
     n_mcmc_steps = int(dataset_length / n_chains)
     step = step_size * torch.ones((n_chains, 1), device=device)
     lp, grad = target_log_prob_and_grad(y)
+    hip_target = getattr(target_log_prob_and_grad, "hip_target", None)
+    from ..additions import ebm_mle
+    if mcmc_type == "mala" and hip_target is not None and ebm_mle.NATIVE_MOVES and y.is_cuda and y.dim() == 2:
+        # all warm-up and sampling steps of all chains in ONE launch (k_langevin_moves); random numbers as configured in ebm_mle
+        y, lp, grad = y.contiguous().float().clone(), lp.contiguous().float().clone(), grad.contiguous().float().clone()
+        got, _, _ = ebm_mle._native_run((hip_target, None), None, y, lp, grad, step.reshape(-1).contiguous().clone(), n_warmup_steps + n_mcmc_steps,
+                                        n_warmup_steps, False, 0.75 if adapt_step_size else 0.0)
+        ret = got.cpu().view((-1, *x_init.shape[1:]))
+        return ret[torch.randperm(ret.shape[0])] if shuffle else ret
     ys = torch.empty((n_mcmc_steps, *y.shape))
     for step_id in range(n_warmup_steps + n_mcmc_steps):
         if mcmc_type == "mala":

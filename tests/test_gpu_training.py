@@ -122,7 +122,7 @@ def test_ema_weights_are_used_for_evaluation(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d,N,B,clip", [(128, 7, 37, 1e4), (100, 5, 64, 0.05), (16, 9, 20, None), (2, 3, 5, 1e4), (61, 4, 48, 0.2)])
+@pytest.mark.parametrize("d,N,B,clip", [(128, 7, 37, 1e4), (100, 5, 64, 0.05), (16, 9, 20, None), (2, 3, 5, 1e4), (61, 4, 48, 0.03)])
 def test_fused_forward_backward_of_the_drift_net_matches_autograd(gpu, d, N, B, clip):
     """sdeng_ctrl_vjp (csrc/grad_kernel.hpp): per-row activations / cotangents of the drift net, the six parameter-gradient products built
     from them and the state gradient, against torch autograd of the same ClippedCtrl in fp64.  Rows per time not a multiple of the

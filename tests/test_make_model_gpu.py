@@ -302,3 +302,74 @@ def test_annealed_samplers_on_hip_densities_match_reference_fixture(gpu, name):
     assert float((steps_out.reshape(m["n_levels"], m["B"], 1).cpu() - c["steps_out"]).abs().max()) < 1e-6
     for k, v in diags.items():
         assert float((torch.as_tensor(v).float().cpu() - c["diag_" + k]).abs().max()) < 1e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_ula", [False, True])
+def test_native_langevin_moves_equal_the_host_composition(gpu, use_ula):
+    """sdeng_langevin_moves (one launch for all moves of a level) against the move-by-move composition of additions/mcmc.py over
+    ``sdeng_dist_eval`` -- same random numbers (torch's generator in the reference's order) -- on a larger case than the fixtures:
+    600 chains, d = 24, 12 moves, per-chain tempering weights and step sizes, step-size adaptation on."""
+    from sde_sampler_lrds_amd import engine as E
+    from sde_sampler_lrds_amd.additions import ebm_mle, mcmc
+    from sde_sampler_lrds_amd.distr.gauss import GMM, IsotropicGauss
+    torch.manual_seed(4)
+    d, B, K = 24, 600, 12
+    target = GMM(dim=d, loc=2.0 * torch.randn(3, d), scale=0.5 + 0.3 * torch.rand(3, d), mixture_weights=torch.tensor([0.5, 0.3, 0.2])).to(gpu)
+    prior = IsotropicGauss(dim=d, scale=2.5).to(gpu)
+    f = ebm_mle.hip_tempered_log_prob_and_grads(target, prior)
+    t = torch.rand(B, 1, device=gpu)
+    x0 = 2.0 * torch.randn(B, d, device=gpu)
+    step0 = (0.02 + 0.05 * torch.rand(B, 1, device=gpu))
+    # host composition
+    torch.manual_seed(11)
+    x, step = x0.clone(), step0.clone()
+    lp, grad = f(t, x)
+    xs_ref = []
+    for _ in range(K):
+        if use_ula:
+            x, lp, grad = mcmc.ula_step(x, lp, grad, lambda y: f(t, y), step)
+        else:
+            x, lp, grad, log_acc = mcmc.mala_step(x, lp, grad, lambda y: f(t, y), step)
+            step = mcmc.heuristics_step_size(step, log_acc, target_acceptance=0.75)
+        xs_ref.append(x.clone())
+    # one launch
+    torch.manual_seed(11)
+    xn = x0.clone()
+    lpn, gn = f(t, xn)
+    lpn, gn, stn = lpn.contiguous().clone(), gn.contiguous().clone(), step0.reshape(-1).clone()
+    got, acc, last = E.langevin_moves(target, prior, xn, lpn, gn, stn, K, t=t.reshape(-1), unadjusted=use_ula, target_acceptance=0.0 if use_ula else 0.75)
+    err = (got - torch.stack(xs_ref)).abs().amax(dim=(0, 2))
+    flipped = int((err > 1e-3).sum())  # an accept / reject decision within round-off of its threshold flips the chain
+    print(f"native moves ({'ULA' if use_ula else 'MALA'}): max |dx| over the chains that made the same decisions {float(err[err <= 1e-3].max()):.2e}; "
+          f"{flipped} of {B} chains flipped a decision")
+    assert flipped <= 2 and float(err[err <= 1e-3].max()) < 2e-5
+    same = err <= 1e-3
+    assert float((stn - step.reshape(-1))[same].abs().max()) < 1e-7 and float((lpn - lp)[same].abs().max()) < 1e-3
+    assert torch.equal(got[-1], xn)
+
+
+@pytest.mark.gpu
+def test_native_moves_with_in_kernel_noise_sample_the_target(gpu):
+    """NATIVE_NOISE (Philox draws inside the kernel): an SMC run moves a wide Gaussian onto a 3-mode mixture with the right mode weights."""
+    from sde_sampler_lrds_amd.additions import ebm_mle
+    from sde_sampler_lrds_amd.distr.gauss import GMM, IsotropicGauss
+    torch.manual_seed(0)
+    d, B, n_levels = 4, 8192, 12
+    loc = torch.tensor([[3.0, 0, 0, 0], [-3.0, 0, 0, 0], [0, 3.0, 0, 0]])
+    wts = torch.tensor([0.5, 0.3, 0.2])
+    target = GMM(dim=d, loc=loc, scale=0.6 * torch.ones(3, d), mixture_weights=wts.clone()).to(gpu)
+    prior = IsotropicGauss(dim=d, scale=3.0).to(gpu)
+    f = ebm_mle.hip_tempered_log_prob_and_grads(target, prior)
+    times = torch.linspace(1.0, 0.0, n_levels, device=gpu).view(-1, 1, 1).repeat(1, B, 1)
+    steps = torch.full((n_levels, B, 1), 0.05, device=gpu)
+    ebm_mle.NATIVE_NOISE = True
+    try:
+        samples, steps, diags = ebm_mle.smc_sampler(prior.sample((B,)), times, f, 8, 4, steps, reweight_threshold=1.0)
+    finally:
+        ebm_mle.NATIVE_NOISE = False
+    final = samples[0, -1]
+    mode = torch.cdist(final, loc.to(gpu)).argmin(dim=1)
+    frac = torch.bincount(mode, minlength=3).float() / B
+    print("native-noise SMC mode fractions", frac.tolist(), "local acc", diags["local_acc"][0].item())
+    assert float((frac.cpu() - wts).abs().max()) < 0.05 and 0.3 < float(diags["local_acc"][0]) <= 1.0
