@@ -15,11 +15,12 @@
 // ------------------------------------------------------------------------------------------------
 // One thread per 16-bit half of the image.  Block (to, kb), part (0 = hi, 1 = lo), lane, j:
 //   w = W[16 to + (lane & 15)][16 (2 kb + j/4) + 4 (lane >> 4) + j%4];  hi = f16(w);  lo = f16((w - hi) * 2^11)
-// Per-matrix power-of-two scale (sim_common.hpp SD_N_SCALES): one block, the four matrices one after the other.
+// Per-matrix power-of-two scale (sim_common.hpp SD_N_SCALES): four blocks, one matrix each.
 __global__ void __launch_bounds__(256) k_weight_scales(PackArgs a) {
   __shared__ float red[256];
   float* sc = a.out + sd_off_scales(a.NT);
-  for (int l = 0; l < 4; ++l) {
+  {
+    const int l = blockIdx.x;
     const float* W = l == 0 ? a.w_in : (l == 1 ? a.w_h1 : (l == 2 ? a.w_h2 : a.w_out));
     const int n = (l == 0 || l == 3) ? SD_H * a.d : SD_H * SD_H;
     float m = 0.0f;
@@ -1026,7 +1027,7 @@ int sd_launch_sample_x0(const sdeng_dist& ds, unsigned lo, unsigned hi, long lon
 // ---- host-side launch wrappers -------------------------------------------------------------------
 int sd_launch_pack(const PackArgs& a, hipStream_t s) {
   const int total = sd_lds_weight_floats(a.NT) * 2 + (a.transpose ? 0 : 3 * 64 + 16 * a.NT);
-  if (!a.transpose) hipLaunchKernelGGL(k_weight_scales, dim3(1), dim3(256), 0, s, a);
+  if (!a.transpose) hipLaunchKernelGGL(k_weight_scales, dim3(4), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_pack_mlp, dim3((total + 255) / 256), dim3(256), 0, s, a);
   return static_cast<int>(hipGetLastError());
 }

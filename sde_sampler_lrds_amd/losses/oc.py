@@ -78,10 +78,15 @@ class _FusedIntegral(torch.autograd.Function):
         ctrl, net = ctx.ctrl, ctx.ctrl.base_model
         cot = zc.view(N, B, d) * grad_s.view(1, B, 1)  # d loss / d u_kb
         r = E.ctrl_vjp(ctrl, t_unique, xs, cot)
-        grads = {net.out_layer.weight: r["dout"].t() @ r["a2"], net.out_layer.bias: r["dout"].sum(0),
-                 net.hidden_layer[1].weight: r["d2"].t() @ r["a1"], net.hidden_layer[1].bias: r["d2"].sum(0),
-                 net.hidden_layer[0].weight: r["d1"].t() @ r["a0"], net.hidden_layer[0].bias: r["d1"].sum(0),
-                 net.input_embed.weight: r["d0"].t() @ r["x"], net.input_embed.bias: r["d0"].sum(0)}
+
+        def outer(dl, act):
+            # dl^T act over all N * B rows.  As ONE GEMM this is 64 x 64 (or d x 64) with K = N * B: hipBLASLt runs it on a handful of
+            # workgroups (180 us each at 512 x 100 rows, rocprofv3); batched over the N times and summed it fills the chip (~10 us).
+            return torch.bmm(dl.view(N, B, -1).transpose(1, 2), act.view(N, B, -1)).sum(0)
+        grads = {net.out_layer.weight: outer(r["dout"], r["a2"]), net.out_layer.bias: r["dout"].sum(0),
+                 net.hidden_layer[1].weight: outer(r["d2"], r["a1"]), net.hidden_layer[1].bias: r["d2"].sum(0),
+                 net.hidden_layer[0].weight: outer(r["d1"], r["a0"]), net.hidden_layer[0].bias: r["d1"].sum(0),
+                 net.input_embed.weight: outer(r["d0"], r["x"]), net.input_embed.bias: r["d0"].sum(0)}
         # time embedding e_t = timestep_embed(t_k): its cotangent is the sum over the particles of d0; the small module itself (2 layers on
         # N rows) is differentiated by torch
         te_params = [p for p in net.timestep_embed.parameters() if p.requires_grad]
