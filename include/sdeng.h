@@ -98,6 +98,9 @@ extern "C" {
                                       ctrl(t, x) - ref_score(t, x), ref_score = the reference drift of `ref`.  Forward forms (LIN / EM) with a
                                       Score / Lerp / CancelDrift control and a diagonal reference; SDENG_E_UNSUPPORTED otherwise. */
 
+#define SDENG_FLAG_REUSE_PACK 64u  /* sdeng_ctrl_vjp only: the packed weight images of an earlier call with the same net are still in the
+                                      workspace -- skip re-packing (a caller that walks the times one by one, e.g. an adjoint recursion) */
+
 /* ---- distributions (the distr package): log-density and score by hand-coded formulas ------------ */
 #define SDENG_DIST_NONE 0
 #define SDENG_DIST_GMM_DIAG 1   /* distr/gauss.py:138-244  GMM / TwoModes / ManyModes (MixtureSameFamily)   */
@@ -278,11 +281,12 @@ int sdeng_philox_normal_steps(uint64_t seed, int32_t step0, int32_t n_steps, int
  * graph that losses/oc.py:83-103 (generative_and_sde_ctrl) builds per step and loss.backward() walks (models/mlp.py:135-143,
  * models/reparam.py:33-43).  Reads desc->{abi_version, d, coef, net, workspace}.  `cot` [M,d] is the cotangent of the control u.
  * Per-row outputs, all [M,64] unless noted:  a0, a1, a2 = gelu of the three hidden pre-activations;  d0, d1, d2 = cotangents of those
- * pre-activations;  dout [M,d] = cot under ClippedCtrl's clip mask;  gx [M,d] (optional) = gradient w.r.t. the state.  The
+ * pre-activations;  dout [M,d] = cot under ClippedCtrl's clip mask;  gx [M,d] (optional) = gradient w.r.t. the state;  u_out [M,d]
+ * (optional) = the control itself.  cot == NULL: forward only (u_out required, the other outputs may be NULL).  The
  * parameter gradients are the caller's six products over the rows: dW_out = dout^T a2, dW_2 = d2^T a1, dW_1 = d1^T a0,
  * dW_in = d0^T x, bias gradients = column sums, cotangent of the time embedding of time k = sum over its rows of d0. */
 int sdeng_ctrl_vjp(const sdeng_desc* desc, int32_t n_times, int32_t rows_per_time, const float* x, const float* cot, float* a0, float* a1,
-                   float* a2, float* d0, float* d1, float* d2, float* dout, float* gx, void* stream);
+                   float* a2, float* d0, float* d1, float* d2, float* dout, float* gx, float* u_out, void* stream);
 size_t sdeng_ctrl_vjp_workspace_bytes(int32_t d, int32_t n_times);
 
 /* Annealed samplers: n_moves Langevin moves of B chains in ONE launch -- mala_step / ula_step of additions/mcmc.py:77-135,

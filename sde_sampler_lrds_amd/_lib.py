@@ -12,7 +12,7 @@ ABI_VERSION = 3
 NCOEF = 16
 
 FORM_LIN, FORM_EM, FORM_CMCD, FORM_EUBO, FORM_CMCD_EUBO = 0, 1, 2, 3, 4
-FLAG_ITO, FLAG_INIT_LOGP, FLAG_TERM_REF, FLAG_TERM_TARGET, FLAG_SPLIT_TILES, FLAG_REMOVE_REF = 1, 2, 4, 8, 16, 32
+FLAG_ITO, FLAG_INIT_LOGP, FLAG_TERM_REF, FLAG_TERM_TARGET, FLAG_SPLIT_TILES, FLAG_REMOVE_REF, FLAG_REUSE_PACK = 1, 2, 4, 8, 16, 32, 64
 SPLIT_TILES_MAX_B = 8192  # SDENG_FLAG_SPLIT_TILES is honoured up to this batch size (sdeng.h, sdeng_api.hip split_eligible)
 DIST_NONE, DIST_GMM_DIAG, DIST_GAUSS_DIAG, DIST_ISO_GAUSS, DIST_PHI4, DIST_LOGREG, DIST_GAUSS_FULL, DIST_RINGS = range(8)
 CTRL_CLIPPED, CTRL_SCORE, CTRL_LERP, CTRL_NONE, CTRL_CANCEL_DRIFT = 0, 1, 2, 3, 4
@@ -103,7 +103,7 @@ def lib() -> C.CDLL:
     L.sdeng_sample_x0.restype = C.c_int
     L.sdeng_sample_x0.argtypes = [C.POINTER(Dist), C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.sdeng_ctrl_vjp.restype = C.c_int
-    L.sdeng_ctrl_vjp.argtypes = [C.POINTER(Desc), C.c_int32, C.c_int32] + [C.c_void_p] * 11
+    L.sdeng_ctrl_vjp.argtypes = [C.POINTER(Desc), C.c_int32, C.c_int32] + [C.c_void_p] * 12
     L.sdeng_ctrl_vjp_workspace_bytes.restype = C.c_size_t
     L.sdeng_ctrl_vjp_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     L.sdeng_langevin_moves.restype = C.c_int

@@ -20,7 +20,7 @@
 struct VjpArgs {
   int M, B, d, N;          // rows, rows per time (row r is evaluated at time r / B), dimension, number of times
   const float* x;          // [M, d]
-  const float* cot;        // [M, d] cotangent of u
+  const float* cot;        // [M, d] cotangent of u; nullptr: forward only (u_out)
   const float* wpack;      // forward image (+ biases + layer scales behind it)
   const float* wpack_t;    // transposed image: [W_out^T | W_2^T | W_1^T | W_in^T] in the slots of [W_in | W_1 | W_2 | W_out]
   const float* temb;       // [N][64]
@@ -29,6 +29,7 @@ struct VjpArgs {
   float *d0, *d1, *d2;     // [M, 64] cotangents of h0, h1, h2
   float* dout;             // [M, d]  cotangent of the net's output (after the clip mask)
   float* gx;               // [M, d]  W_in^T d0, or nullptr
+  float* u_out;            // [M, d]  the control itself (after the clip), or nullptr
   float* trash;
   int ntiles;
 };
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_vjp(const Vjp
       }
       h1[t] = load_tile4(bias + 64, t, g);
     }
-    store_h(a.a0, trash, row, live, g, act);
+    if (a.a0) store_h(a.a0, trash, row, live, g, act);
     dense<SD_HT, SD_HT>(act, h1, lds + sd_off_wh1(NT), lane);
 #pragma unroll
     for (int t = 0; t < SD_HT; ++t) {
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_vjp(const Vjp
       for (int r = 0; r < 4; ++r) act[t][r] = gelu_fast(h1[t][r]);
       h2[t] = load_tile4(bias + 128, t, g);
     }
-    store_h(a.a1, trash, row, live, g, act);
+    if (a.a1) store_h(a.a1, trash, row, live, g, act);
     dense<SD_HT, SD_HT>(act, h2, lds + sd_off_wh2(NT), lane);
 #pragma unroll
     for (int t = 0; t < SD_HT; ++t) {
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_vjp(const Vjp
 #pragma unroll
       for (int r = 0; r < 4; ++r) act[t][r] = gelu_fast(h2[t][r]);
     }
-    store_h(a.a2, trash, row, live, g, act);
+    if (a.a2) store_h(a.a2, trash, row, live, g, act);
     __builtin_amdgcn_sched_barrier(0);
     // ---- output layer: only the clip mask of ClippedCtrl (torch.clip passes the gradient where min <= u <= max; NaN: nowhere) ----
     f32x4 dl[NT];
@@ -146,18 +147,25 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_ctrl_vjp(const Vjp
       const HidSplit hs = split_hidden(act);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        f32x4 c = load_quad(a.cot, row, a.d, live, t, g);
-        if (a.clip_model > 0.0f) {
+        f32x4 c = a.cot ? load_quad(a.cot, row, a.d, live, t, g) : zero;
+        if (a.clip_model > 0.0f || a.u_out) {
           f32x4 u[1];
           mlp_out_tiles<NT, 1>(hs, a.wpack, bias, t, lane, u, ns.inv_out);  // A operands through L2
+          if (a.clip_model > 0.0f) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) c[r] = (__builtin_fabsf(u[0][r]) <= a.clip_model) ? c[r] : 0.0f;
+            for (int r = 0; r < 4; ++r) {
+              c[r] = (__builtin_fabsf(u[0][r]) <= a.clip_model) ? c[r] : 0.0f;
+              u[0][r] = clampf(u[0][r], a.clip_model);
+            }
+          }
+          if (a.u_out) store_quad(a.u_out, trash, row, a.d, live, t, g, u[0]);
         }
         dl[t] = c;
-        store_quad(a.dout, trash, row, a.d, live, t, g, c);
+        if (a.dout) store_quad(a.dout, trash, row, a.d, live, t, g, c);
         __builtin_amdgcn_sched_barrier(0);  // one output tile at a time: hoisted, the A operands of all tiles (read through L2) spill
       }
     }
+    if (!a.cot) continue;  // forward only (wave-uniform)
     __builtin_amdgcn_sched_barrier(0);
     // ---- backward through the three hidden activations ----
     f32x4 dh[SD_HT], gacc[SD_HT];

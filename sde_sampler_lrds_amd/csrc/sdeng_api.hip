@@ -713,9 +713,11 @@ extern "C" size_t sdeng_ctrl_vjp_workspace_bytes(int32_t d, int32_t n_times) {
   return vjp_floats(tiles_exact(d), n_times, &a, &b, &c) * sizeof(float);
 }
 extern "C" int sdeng_ctrl_vjp(const sdeng_desc* d, int32_t n_times, int32_t rows_per_time, const float* x, const float* cot, float* a0,
-                              float* a1, float* a2, float* d0, float* d1, float* d2, float* dout, float* gx, void* stream) {
+                              float* a1, float* a2, float* d0, float* d1, float* d2, float* dout, float* gx, float* u_out, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!d || !x || !cot || !a0 || !a1 || !a2 || !d0 || !d1 || !d2 || !dout) return fail(SDENG_E_INVALID, "null argument");
+  if (!d || !x) return fail(SDENG_E_INVALID, "null argument");
+  if (cot && (!a0 || !a1 || !a2 || !d0 || !d1 || !d2 || !dout)) return fail(SDENG_E_INVALID, "backward pass: every per-row output is required");
+  if (!cot && !u_out) return fail(SDENG_E_INVALID, "nothing to compute: no cotangent and no u_out");
   if (d->abi_version != SDENG_ABI_VERSION) return fail(SDENG_E_INVALID, "ABI version %d, library has %d", d->abi_version, SDENG_ABI_VERSION);
   if (d->d < 1 || d->d > 128 || n_times < 1 || rows_per_time < 1 || !d->coef) return fail(SDENG_E_INVALID, "bad sizes (1 <= d <= 128, n_times, rows_per_time >= 1) or null coef");
   if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED) return fail(SDENG_E_UNSUPPORTED, "ctrl_vjp: ClippedCtrl around the FourierMLP (ctrl_kind %d given)", d->net.ctrl_kind);
@@ -728,15 +730,17 @@ extern "C" int sdeng_ctrl_vjp(const sdeng_desc* d, int32_t n_times, int32_t rows
   const size_t need = vjp_floats(DT, n_times, &o_wt, &o_temb, &o_trash) * sizeof(float);
   if (!d->workspace || d->workspace_bytes < need) return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, need);
   float* ws = static_cast<float*>(d->workspace);
-  PackArgs pk;
-  pk.NT = DT; pk.d = d->d;
-  pk.w_in = d->net.w_in; pk.b_in = d->net.b_in; pk.w_h1 = d->net.w_h1; pk.b_h1 = d->net.b_h1;
-  pk.w_h2 = d->net.w_h2; pk.b_h2 = d->net.b_h2; pk.w_out = d->net.w_out; pk.b_out = d->net.b_out;
-  pk.out = ws; pk.transpose = 0; pk.scales = nullptr;
-  SD_HIP(sd_launch_pack(pk, s));
-  PackArgs pt = pk;
-  pt.out = ws + o_wt; pt.transpose = 1; pt.scales = ws + sd_off_scales(DT);
-  SD_HIP(sd_launch_pack(pt, s));
+  if (!(d->flags & SDENG_FLAG_REUSE_PACK)) {  // (a caller stepping through the times one by one packs once: the images stay valid in the workspace)
+    PackArgs pk;
+    pk.NT = DT; pk.d = d->d;
+    pk.w_in = d->net.w_in; pk.b_in = d->net.b_in; pk.w_h1 = d->net.w_h1; pk.b_h1 = d->net.b_h1;
+    pk.w_h2 = d->net.w_h2; pk.b_h2 = d->net.b_h2; pk.w_out = d->net.w_out; pk.b_out = d->net.b_out;
+    pk.out = ws; pk.transpose = 0; pk.scales = nullptr;
+    SD_HIP(sd_launch_pack(pk, s));
+    PackArgs pt = pk;
+    pt.out = ws + o_wt; pt.transpose = 1; pt.scales = ws + sd_off_scales(DT);
+    SD_HIP(sd_launch_pack(pt, s));
+  }
   TimeEmbedArgs te;
   te.te = d->net.t_embed; te.coef = d->coef; te.col = 0; te.t_direct = 0; te.t_value = 0.0f; te.clip = 0.0f;
   te.out = ws + o_temb;
@@ -746,7 +750,7 @@ extern "C" int sdeng_ctrl_vjp(const sdeng_desc* d, int32_t n_times, int32_t rows
   a.M = static_cast<int>(M); a.B = rows_per_time; a.d = d->d; a.N = n_times;
   a.x = x; a.cot = cot; a.wpack = ws; a.wpack_t = ws + o_wt; a.temb = ws + o_temb;
   a.clip_model = d->net.clip_model;
-  a.a0 = a0; a.a1 = a1; a.a2 = a2; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.dout = dout; a.gx = gx;
+  a.a0 = a0; a.a1 = a1; a.a2 = a2; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.dout = dout; a.gx = gx; a.u_out = u_out;
   a.trash = ws + o_trash;
   a.ntiles = static_cast<int>((M + 15) / 16);
   SD_HIP(kVjpTable[dt_index(DT)](a, grid_for(a.ntiles), s));

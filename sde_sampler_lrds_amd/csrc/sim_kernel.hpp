@@ -126,7 +126,11 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
   static_assert(SC != SC_LOGREG || (REF == RF_NONE && NT <= 4), "in-loop logistic-regression score: no reference, d <= 64");
   const float* bias = a.wpack + sd_off_bias(NT);
   const NetScale ns = load_net_scale(bias, NT);
+#ifdef SD_NO_RANGE_GUARD  // A/B builds only (tools/variant_lib.sh): the step loop without the range guard of DESIGN 4b
+  const bool scaled_net = false;
+#else
   const bool scaled_net = ns.any();
+#endif
   // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)
 #ifdef SD_DBG_NODMA
   constexpr bool ref_lds = false;
@@ -480,7 +484,11 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
         else mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
         // (not in the kernels whose reference / target score puts the state itself through split-f16 products -- matrix-pipe and
         // full-covariance mixtures, the in-loop logistic-regression score: those products have no twin, the guard would be half a guard)
+#ifdef SD_NO_RANGE_GUARD
+        constexpr bool range_guard = false;
+#else
         constexpr bool range_guard = REF != RF_GMM_MM && REF != RF_GMM_FULL && SC != SC_LOGREG;
+#endif
         if (t0 == 0) {
           // A state or an activation beyond f16's range (65 504) turned into inf in a split operand: every output of that particle is
           // then inf or NaN, so ONE compare on the first output register finds it.  The net of this step is evaluated again through

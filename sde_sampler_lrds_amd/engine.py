@@ -735,8 +735,62 @@ def ctrl_vjp(ctrl, t_unique: torch.Tensor, xs: torch.Tensor, cot: torch.Tensor, 
     desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel()
     L.check(lib.sdeng_ctrl_vjp(C.byref(desc), N, B, x2.data_ptr(), c2.data_ptr(), hid[0].data_ptr(), hid[1].data_ptr(), hid[2].data_ptr(),
                                hid[3].data_ptr(), hid[4].data_ptr(), hid[5].data_ptr(), dout.data_ptr(), gx.data_ptr() if want_gx else None,
-                               _stream_ptr(device)))
+                               None, _stream_ptr(device)))
     return dict(x=x2, a0=hid[0], a1=hid[1], a2=hid[2], d0=hid[3], d1=hid[4], d2=hid[5], dout=dout, gx=gx)
+
+
+class VjpSession:
+    """sdeng_ctrl_vjp for a caller that walks the N times one by one (the adjoint recursion of KL training): the weight images are packed
+    once, ``forward_u`` evaluates the control on all N * B rows, ``step(k, cot_k)`` runs the fused forward + backward of time k alone
+    (cotangent [B, d]) -- its per-row arrays land in row block k of the session's [N * B, .] arrays -- and returns the state gradient
+    [B, d].  After the walk the arrays are exactly what ``ctrl_vjp`` returns for the whole batch."""
+
+    def __init__(self, ctrl, t_unique: torch.Tensor, xs: torch.Tensor):
+        require_gpu(xs)
+        self.lib, self.device, self.keep = L.lib(), xs.device, []
+        self.N, self.B, self.d = xs.shape
+        N, B, d = xs.shape
+        self.desc = L.Desc()
+        self.desc.abi_version = L.ABI_VERSION
+        self.desc.net = net_desc(ctrl, self.device, self.keep)
+        if self.desc.net.ctrl_kind != L.CTRL_CLIPPED:
+            raise UnsupportedByEngine("ctrl_vjp: ClippedCtrl only")
+        self.desc.d = d
+        self.coef = torch.zeros(N, L.NCOEF, dtype=torch.float32, device=self.device)
+        self.coef[:, 0] = t_unique.detach().to(device=self.device, dtype=torch.float32).reshape(-1)
+        self.x = xs.detach().to(torch.float32).contiguous().view(N * B, d)
+        self.hid = torch.empty(6, N * B, 64, dtype=torch.float32, device=self.device)
+        self.dout = torch.empty(N * B, d, dtype=torch.float32, device=self.device)
+        self.gx = torch.empty(B, d, dtype=torch.float32, device=self.device)
+        self.ws = torch.empty(self.lib.sdeng_ctrl_vjp_workspace_bytes(d, N), dtype=torch.uint8, device=self.device)  # its own: the images must survive
+        self.desc.workspace, self.desc.workspace_bytes = self.ws.data_ptr(), self.ws.numel()
+        self.packed = False
+
+    def forward_u(self) -> torch.Tensor:
+        u = torch.empty(self.N * self.B, self.d, dtype=torch.float32, device=self.device)
+        self.desc.coef, self.desc.flags = self.coef.data_ptr(), 0
+        L.check(self.lib.sdeng_ctrl_vjp(C.byref(self.desc), self.N, self.B, self.x.data_ptr(), None, None, None, None, None, None, None, None, None,
+                                        u.data_ptr(), _stream_ptr(self.device)))
+        self.packed = True
+        return u.view(self.N, self.B, self.d)
+
+    def step(self, k: int, cot: torch.Tensor) -> torch.Tensor:
+        B, d = self.B, self.d
+        c = cot.detach().to(torch.float32).contiguous()
+        self.keep.append(c)
+        self.desc.coef = self.coef.data_ptr() + 4 * L.NCOEF * k
+        self.desc.flags = L.FLAG_REUSE_PACK if self.packed else 0
+        row = lambda t, width: t.data_ptr() + 4 * width * B * k  # noqa: E731
+        L.check(self.lib.sdeng_ctrl_vjp(C.byref(self.desc), 1, B, row(self.x, d), c.data_ptr(), row(self.hid[0], 64), row(self.hid[1], 64),
+                                        row(self.hid[2], 64), row(self.hid[3], 64), row(self.hid[4], 64), row(self.hid[5], 64), row(self.dout, d),
+                                        self.gx.data_ptr(), None, _stream_ptr(self.device)))
+        self.packed = True
+        self.keep.clear()
+        return self.gx
+
+    def arrays(self):
+        h = self.hid
+        return dict(x=self.x, a0=h[0], a1=h[1], a2=h[2], d0=h[3], d1=h[4], d2=h[5], dout=self.dout, gx=None)
 
 
 def ctrl_forward(ctrl, t: float, x: torch.Tensor, score_gain=1.0, lerp_w=0.0):

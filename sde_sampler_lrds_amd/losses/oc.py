@@ -75,28 +75,33 @@ class _FusedIntegral(torch.autograd.Function):
     def backward(ctx, grad_s):
         t_unique, xs, zc = ctx.saved_tensors
         N, B, d = ctx.shape
-        ctrl, net = ctx.ctrl, ctx.ctrl.base_model
         cot = zc.view(N, B, d) * grad_s.view(1, B, 1)  # d loss / d u_kb
-        r = E.ctrl_vjp(ctrl, t_unique, xs, cot)
-
-        def outer(dl, act):
-            # dl^T act over all N * B rows.  As ONE GEMM this is 64 x 64 (or d x 64) with K = N * B: hipBLASLt runs it on a handful of
-            # workgroups (180 us each at 512 x 100 rows, rocprofv3); batched over the N times and summed it fills the chip (~10 us).
-            return torch.bmm(dl.view(N, B, -1).transpose(1, 2), act.view(N, B, -1)).sum(0)
-        grads = {net.out_layer.weight: outer(r["dout"], r["a2"]), net.out_layer.bias: r["dout"].sum(0),
-                 net.hidden_layer[1].weight: outer(r["d2"], r["a1"]), net.hidden_layer[1].bias: r["d2"].sum(0),
-                 net.hidden_layer[0].weight: outer(r["d1"], r["a0"]), net.hidden_layer[0].bias: r["d1"].sum(0),
-                 net.input_embed.weight: outer(r["d0"], r["x"]), net.input_embed.bias: r["d0"].sum(0)}
-        # time embedding e_t = timestep_embed(t_k): its cotangent is the sum over the particles of d0; the small module itself (2 layers on
-        # N rows) is differentiated by torch
-        te_params = [p for p in net.timestep_embed.parameters() if p.requires_grad]
-        if te_params:
-            with torch.enable_grad():
-                e = net.timestep_embed(t_unique.view(-1, 1))
-                te_grads = torch.autograd.grad(e, te_params, grad_outputs=r["d0"].view(N, B, 64).sum(1), allow_unused=True)
-            grads.update({p: g for p, g in zip(te_params, te_grads) if g is not None})
-        params = [p for p in ctrl.parameters() if p.requires_grad]
+        grads = vjp_param_grads(ctx.ctrl, t_unique, E.ctrl_vjp(ctx.ctrl, t_unique, xs, cot), N, B)
+        params = [p for p in ctx.ctrl.parameters() if p.requires_grad]
         return (None, None, None, None) + tuple(grads.get(p) for p in params)
+
+
+def vjp_param_grads(ctrl, t_unique, r, N, B):
+    """Per-row arrays of ``sdeng_ctrl_vjp`` (include/sdeng.h) -> {parameter: gradient} for a ClippedCtrl over a FourierMLP."""
+    net = ctrl.base_model
+
+    def outer(dl, act):
+        # dl^T act over all N * B rows.  As ONE GEMM this is 64 x 64 (or d x 64) with K = N * B: hipBLASLt runs it on a handful of
+        # workgroups (180 us each at 512 x 100 rows, rocprofv3); batched over the N times and summed it fills the chip (~10 us).
+        return torch.bmm(dl.view(N, B, -1).transpose(1, 2), act.view(N, B, -1)).sum(0)
+    grads = {net.out_layer.weight: outer(r["dout"], r["a2"]), net.out_layer.bias: r["dout"].sum(0),
+             net.hidden_layer[1].weight: outer(r["d2"], r["a1"]), net.hidden_layer[1].bias: r["d2"].sum(0),
+             net.hidden_layer[0].weight: outer(r["d1"], r["a0"]), net.hidden_layer[0].bias: r["d1"].sum(0),
+             net.input_embed.weight: outer(r["d0"], r["x"]), net.input_embed.bias: r["d0"].sum(0)}
+    # time embedding e_t = timestep_embed(t_k): its cotangent is the sum over the particles of d0; the small module itself (2 layers on
+    # N rows) is differentiated by torch
+    te_params = [p for p in net.timestep_embed.parameters() if p.requires_grad]
+    if te_params:
+        with torch.enable_grad():
+            e = net.timestep_embed(t_unique.view(-1, 1))
+            te_grads = torch.autograd.grad(e, te_params, grad_outputs=r["d0"].view(N, B, 64).sum(1), allow_unused=True)
+        grads.update({p: g for p, g in zip(te_params, te_grads) if g is not None})
+    return grads
 
 
 class _IntegralPass(torch.nn.Module):
@@ -321,10 +326,34 @@ class BaseOCLoss:
         params = [p for p in ctrl.parameters() if p.requires_grad]
         grads = [torch.zeros_like(p) for p in params]
         coef = self._coef(ts, x.device, **(coef_kw or {}))
+        fused = self.fused_training and type(ctrl).__name__ == "ClippedCtrl" and type(getattr(ctrl, "base_model", None)).__name__ == "FourierMLP"
         with torch.enable_grad():
             xN = x_n.detach().requires_grad_(True)
             lam, = torch.autograd.grad((w * terminal(xN).view(B, 1)).sum(), xN)
-            for k in range(N - 1, -1, -1):
+            if fused:
+                # ClippedCtrl over the FourierMLP (every RDS / LRDS solver): the control's part of each step's vector-Jacobian product is
+                # the fused HIP forward + backward of that time step (sdeng_ctrl_vjp; weights packed once per call), the reference score's
+                # part a small torch VJP; the parameter gradients come from the per-row arrays at the end, as in log-variance training.
+                sess = E.VjpSession(ctrl, coef[:, 0], xs[:-1])
+                u_all = sess.forward_u()
+                for k in range(N - 1, -1, -1):
+                    c, u, zk = coef[k], u_all[k], z[k]
+                    if lin:
+                        g = c[2] * lam + w * (2.0 * c[4] * u + (c[5] * zk if ito else 0.0))
+                    else:
+                        g = (c[2] * c[4]) * lam + w * (c[4] * u + (c[5] * zk if ito else 0.0))
+                    gx = sess.step(k, g)
+                    jl = None
+                    if reference_ctrl is not None:
+                        xk = xs[k].detach().requires_grad_(True)
+                        jl, = torch.autograd.grad((reference_ctrl(c[0], xk) * lam).sum(), xk)
+                    if lin:
+                        lam = c[1] * lam + gx if jl is None else c[1] * lam + c[2] * jl + gx
+                    else:
+                        lam = (1.0 + c[4] * c[1]) * lam + gx if jl is None else (1.0 + c[4] * c[1]) * lam + (c[4] * c[3]) * jl + gx
+                found = vjp_param_grads(ctrl, coef[:, 0].contiguous(), sess.arrays(), N, B)
+                grads = [found.get(p, torch.zeros_like(p)) for p in params]
+            for k in (range(N - 1, -1, -1) if not fused else ()):
                 c = coef[k]
                 xk = xs[k].detach().requires_grad_(True)
                 u = ctrl(c[0], xk)
