@@ -480,8 +480,12 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       auto out_group = [&](auto otc, int t0) __attribute__((always_inline)) {
         constexpr int OT = decltype(otc)::value;
         f32x4 u[OT];
+#if defined(SD_GUARD_AB_NOSEL) || defined(SD_GUARD_AB_NOCOLD)  // A/B builds only: what do the per-group selection / the cold code cost?
+        mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
+#else
         if (__builtin_expect(safe_net, 0)) mlp_out_tiles_safe<NT, OT>(hs, hid_rs, lds, bias, t0, lane, u, ns.inv_out);
         else mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
+#endif
         // (not in the kernels whose reference / target score puts the state itself through split-f16 products -- matrix-pipe and
         // full-covariance mixtures, the in-loop logistic-regression score: those products have no twin, the guard would be half a guard)
 #ifdef SD_NO_RANGE_GUARD
@@ -495,12 +499,17 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
           // the range-safe twin (per-particle power-of-two scaling of every layer's input) -- x has not been touched yet.  The
           // reference's fp32 GEMMs stay finite there, and so does this; inputs that are non-finite themselves stay non-finite.
           const bool bad = range_guard && !(__builtin_fabsf(u[0][0]) <= 3.0e38f);
-          if (__builtin_expect(scaled_net || __builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+          const bool trip = scaled_net | (__builtin_amdgcn_ballot_w64(bad) != 0);
+          if (__builtin_expect(trip, 0)) {
             asm volatile("" ::: "memory");  // nothing of the cold path is to be prepared ahead of this test
             safe_net = true;
+#ifndef SD_GUARD_AB_NOCOLD
             mlp_hidden_safe<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane, ns);
             hid_rs = split_hidden_safe(hid, hs);
             mlp_out_tiles_safe<NT, OT>(hs, hid_rs, lds, bias, t0, lane, u, ns.inv_out);
+#else
+            hid_rs = u[0][1];
+#endif
             asm volatile("" ::: "memory");
           }
         }
