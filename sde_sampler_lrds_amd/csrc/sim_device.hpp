@@ -402,6 +402,19 @@ SD_INLINE void mlp_out_tiles_safe(const HidSplit& hs, float rs, const float* lds
     for (int r = 0; r < 4; ++r) u[o][r] = __builtin_fmaf(u[o][r], rs, b[r]) * inv_out;
   }
 }
+// The plain output layer applied to the split of hid * sigma (range-safe step) returns acc = b 2^e + sigma 2^e (W a), b 2^e being the
+// stored bias it starts from: (acc - b 2^e) / sigma + b 2^e, times 2^-e, is W a + b.  (acc - b 2^e is formed in fp32 from an fp32 sum that
+// began with b 2^e: the difference is exact to an ulp of the larger term, like any fp32 evaluation of W a + b.)
+template <int OT>
+SD_INLINE void out_tiles_unscale(f32x4 (&u)[OT], const float* bias, int t0, int lane, float rs, float inv_out) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+    const f32x4 b = load_tile4(bias + 192, t0 + o, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[o][r] = __builtin_fmaf(u[o][r] - b[r], rs, b[r]) * inv_out;
+  }
+}
 // the last hidden activation of the safe path, split with its per-particle factor; returns 1 / sigma
 SD_INLINE float split_hidden_safe(const f32x4 (&a)[SD_HT], HidSplit& s) {
   const float sg = row_downscale<SD_HT>(a);

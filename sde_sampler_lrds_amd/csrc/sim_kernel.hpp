@@ -480,12 +480,10 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       auto out_group = [&](auto otc, int t0) __attribute__((always_inline)) {
         constexpr int OT = decltype(otc)::value;
         f32x4 u[OT];
-#if defined(SD_GUARD_AB_NOSEL) || defined(SD_GUARD_AB_NOCOLD)  // A/B builds only: what do the per-group selection / the cold code cost?
+        // ONE copy of the output layer in the step loop: a step that went through the range-safe twin (below, first group) left the split
+        // of hid * sigma in `hs`; the plain product then gives b 2^e + sigma 2^e W a, which out_tiles_unscale turns into (W a + b)
         mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
-#else
-        if (__builtin_expect(safe_net, 0)) mlp_out_tiles_safe<NT, OT>(hs, hid_rs, lds, bias, t0, lane, u, ns.inv_out);
-        else mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
-#endif
+        if (__builtin_expect(safe_net, 0)) out_tiles_unscale<OT>(u, bias, t0, lane, hid_rs, ns.inv_out);
         // (not in the kernels whose reference / target score puts the state itself through split-f16 products -- matrix-pipe and
         // full-covariance mixtures, the in-loop logistic-regression score: those products have no twin, the guard would be half a guard)
 #ifdef SD_NO_RANGE_GUARD
@@ -503,13 +501,10 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
           if (__builtin_expect(trip, 0)) {
             asm volatile("" ::: "memory");  // nothing of the cold path is to be prepared ahead of this test
             safe_net = true;
-#ifndef SD_GUARD_AB_NOCOLD
             mlp_hidden_safe<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane, ns);
             hid_rs = split_hidden_safe(hid, hs);
-            mlp_out_tiles_safe<NT, OT>(hs, hid_rs, lds, bias, t0, lane, u, ns.inv_out);
-#else
-            hid_rs = u[0][1];
-#endif
+            mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
+            out_tiles_unscale<OT>(u, bias, t0, lane, hid_rs, ns.inv_out);
             asm volatile("" ::: "memory");
           }
         }
