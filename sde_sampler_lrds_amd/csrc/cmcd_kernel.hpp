@@ -25,10 +25,14 @@ enum { CT_LOGREG = 0, CT_GMM = 1, CT_PHI4 = 2 };  // target kind is a template p
 
 // TWO = true also returns b2, the drift with a second pair of annealing weights (the noising loop of compute_eubo
 // needs drift(t, y) for the cost and drift(s, y) for the next move: same scores, two mixes)
-template <int NT, int TGT, bool TWO = false>
+//
+// The results leave one 16 x 16 tile at a time through sink(t, u_t, b_t, b2_t) (t is a compile-time unrolled index).  d <= 64: the drift is
+// mixed and clipped ahead of the net, as the registers allow.  d > 64 (NT > 4): u[NT], b[NT] beside x, w_s, the normals and the target
+// score do not fit 256 registers (452-844 B of scratch per lane in round 2), so the drift of a tile is mixed when the output layer reaches
+// that tile and the caller folds the tile into its sums at once; only the target score stays live across the net.
+template <int NT, int TGT, bool TWO = false, class Sink>
 SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float w_t, float w_1mt, const float* lds,
-                         const float* bias, const NetScale& ns, int lane, f32x4 (&u)[NT], f32x4 (&b)[NT], f32x4 (&b2)[NT], float w2_t = 0.0f,
-                         float w2_1mt = 0.0f) {
+                         const float* bias, const NetScale& ns, int lane, float w2_t, float w2_1mt, Sink&& sink) {
   constexpr int KB = (NT + 1) / 2;
   const int g = lane >> 4;
   const SimArgs& s = a.s;
@@ -56,80 +60,70 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
     else logreg_score<NT, true>(x, xh, xl, s.lr, s.d, s.lr.image, lane, ts);
   }
 
-  // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
   const float hg2 = 0.5f * (s.cmcd_g * s.cmcd_g);
-  if (a.prec_pack) {  // GaussFull: -P (w - mu)   distr/gauss.py:129-135
-    f32x4 df[NT];
+  if constexpr (NT <= 4) {
+    // ---- annealed drift: 0.5 g^2 clip(score_pi * t/T + score_prior * (1 - t/T)) ----
+    f32x4 b[NT], b2[TWO ? NT : 1];
+    if (a.prec_pack) {  // GaussFull: -P (w - mu)   distr/gauss.py:129-135
+      f32x4 df[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) df[t] = x[t] - load_tile4(a.prior_loc, t, g);
-    f16x8 dh[KB], dl[KB];
-    split_tiles<NT>(df, dh, dl);
+      for (int t = 0; t < NT; ++t) df[t] = x[t] - load_tile4(a.prior_loc, t, g);
+      f16x8 dh[KB], dl[KB];
+      split_tiles<NT>(df, dh, dl);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {  // one output tile at a time: 2*KB A-operand vectors live instead of 2*KB*NT
-      f32x4 ps[1] = {zero}, pm[1] = {zero};
-      dense_pre<KB, 1>(dh, dl, ps, pm, reinterpret_cast<const f16x8*>(a.prec_pack) + static_cast<size_t>(t) * KB * 2 * 64, lane);
-      fold_lo<1>(ps, pm);
+      for (int t = 0; t < NT; ++t) {  // one output tile at a time: 2*KB A-operand vectors live instead of 2*KB*NT
+        f32x4 ps[1] = {zero}, pm[1] = {zero};
+        dense_pre_buf<KB, 1>(dh, dl, ps, pm, image_rsrc(a.prec_pack, NT * KB * 2 * 1024), static_cast<uint32_t>(t) * KB * 2 * 1024, lane);
+        fold_lo<1>(ps, pm);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        b[t][r] = ts[t][r] * w_t + (-ps[0][r]) * w_1mt;
-        if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + (-ps[0][r]) * w2_1mt;
-      }
-    }
-  } else if (s.prior.kind == SDENG_DIST_GAUSS_DIAG) {  // Gauss.score (score_gauss, distr/gauss.py:124-126)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const f32x4 pv = gauss_score_tile<NT>(x, s.prior.tab, g, t);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        b[t][r] = ts[t][r] * w_t + pv[r] * w_1mt;
-        if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + pv[r] * w2_1mt;
-      }
-    }
-  } else {  // IsotropicGauss.score  distr/gauss.py:764-766
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = feat_live<NT>(t, r, 4 * g, s.d) ? (a.iso_loc - x[t][r]) * a.inv_iso_var : 0.0f;
-        b[t][r] = ts[t][r] * w_t + pv * w_1mt;
-        if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + pv * w2_1mt;
-      }
-  }
-  // uniform run-time switches (clips on / off, control kind) are tested once per tile, never per element: a scalar branch per
-  // element stalls issue (sim_kernel.hpp, add_ctrl_score_tile)
-  // (d > 64 keeps the plain per-element clamps: that instantiation spills, and the tile-level form made it 7 % slower)
-  const bool clip_b = s.cmcd_clip > 0.0f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    b[t] = b[t] * hg2;
-    if constexpr (TWO) b2[t] = b2[t] * hg2;
-    if constexpr (NT <= 4) {
-      if (clip_b) clamp_tile_rare(b[t], s.cmcd_clip);
-      if constexpr (TWO) {
-        if (clip_b) clamp_tile_rare(b2[t], s.cmcd_clip);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (clip_b) b[t][r] = clampf(b[t][r], s.cmcd_clip);
-        if constexpr (TWO) {
-          if (clip_b) b2[t][r] = clampf(b2[t][r], s.cmcd_clip);
+        for (int r = 0; r < 4; ++r) {
+          b[t][r] = ts[t][r] * w_t + (-ps[0][r]) * w_1mt;
+          if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + (-ps[0][r]) * w2_1mt;
         }
       }
-    }
-  }
-
-  // ---- control ----
-  f32x4 hid[SD_HT];
-  mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane, ns);
-  __builtin_amdgcn_s_setprio(1);  // end of the matrix phase (raised at the top of this function); the rest of the step runs at 1
-  const HidSplit hs = split_hidden(hid);
-  const float st = s.stheta ? s.stheta[ki] : 1.0f;
+    } else if (s.prior.kind == SDENG_DIST_GAUSS_DIAG) {  // Gauss.score (score_gauss, distr/gauss.py:124-126)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    f32x4 o[1];
-    mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, o, ns.inv_out);
-    if constexpr (NT <= 4) {
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 pv = gauss_score_tile<NT>(x, s.prior.tab, g, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          b[t][r] = ts[t][r] * w_t + pv[r] * w_1mt;
+          if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + pv[r] * w2_1mt;
+        }
+      }
+    } else {  // IsotropicGauss.score  distr/gauss.py:764-766
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = feat_live<NT>(t, r, 4 * g, s.d) ? (a.iso_loc - x[t][r]) * a.inv_iso_var : 0.0f;
+          b[t][r] = ts[t][r] * w_t + pv * w_1mt;
+          if constexpr (TWO) b2[t][r] = ts[t][r] * w2_t + pv * w2_1mt;
+        }
+    }
+    // uniform run-time switches (clips on / off, control kind) are tested once per tile, never per element: a scalar branch per
+    // element stalls issue (sim_kernel.hpp, add_ctrl_score_tile)
+    const bool clip_b = s.cmcd_clip > 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      b[t] = b[t] * hg2;
+      if (clip_b) clamp_tile_rare(b[t], s.cmcd_clip);
+      if constexpr (TWO) {
+        b2[t] = b2[t] * hg2;
+        if (clip_b) clamp_tile_rare(b2[t], s.cmcd_clip);
+      }
+    }
+
+    // ---- control ----
+    f32x4 hid[SD_HT];
+    mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane, ns);
+    __builtin_amdgcn_s_setprio(1);  // end of the matrix phase (raised at the top of this function); the rest of the step runs at 1
+    const HidSplit hs = split_hidden(hid);
+    const float st = s.stheta ? s.stheta[ki] : 1.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 o[1];
+      mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, o, ns.inv_out);
       if (s.clip_model > 0.0f) clamp_tile_rare(o[0], s.clip_model);
       if (s.ctrl_kind == SDENG_CTRL_SCORE) {
         f32x4 sv = ts[t];
@@ -141,7 +135,44 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
           o[0][r] = o[0][r] + v;
         }
       }
-    } else {
+      sink(t, o[0], b[t], b2[TWO ? t : 0]);
+    }
+  } else {
+    // ---- d > 64: control first, the drift of a tile beside its control ----
+    const bool clip_b = s.cmcd_clip > 0.0f;
+    const float st = s.stheta ? s.stheta[ki] : 1.0f;
+    f32x4 hid[SD_HT];
+    mlp_hidden_pre<NT>(xh, xl, hid, lds, bias, s.temb + static_cast<size_t>(ki) * SD_H, lane, ns);
+    __builtin_amdgcn_s_setprio(1);
+    const HidSplit hs = split_hidden(hid);
+    f16x8 dh[KB], dl[KB];
+    const bool full_prior = a.prec_pack != nullptr;
+    if (full_prior) {  // split of (w - mu), the B operand of every row block of the precision image: AFTER the hidden layers, in the registers
+      f32x4 df[NT];    // the split of the state occupied until then
+#pragma unroll
+      for (int t = 0; t < NT; ++t) df[t] = x[t] - load_tile4(a.prior_loc, t, g);
+      split_tiles<NT>(df, dh, dl);
+    }
+    const bool diag_prior = s.prior.kind == SDENG_DIST_GAUSS_DIAG;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      asm volatile("" ::: "memory");  // one tile's A operands at a time
+      __builtin_amdgcn_sched_barrier(0);  // ... and one tile's products: left free, the scheduler interleaves all NT independent tiles
+      f32x4 o[1];
+      mlp_out_tiles<NT, 1>(hs, lds, bias, t, lane, o, ns.inv_out);
+      f32x4 pv;
+      if (full_prior) {  // GaussFull: -P (w - mu)   distr/gauss.py:129-135
+        f32x4 ps[1] = {zero}, pm[1] = {zero};
+        dense_pre_buf<KB, 1>(dh, dl, ps, pm, image_rsrc(a.prec_pack, NT * KB * 2 * 1024), static_cast<uint32_t>(t) * KB * 2 * 1024, lane);
+        fold_lo<1>(ps, pm);
+        pv = f32x4{-ps[0][0], -ps[0][1], -ps[0][2], -ps[0][3]};
+      } else if (diag_prior) {  // Gauss.score (score_gauss, distr/gauss.py:124-126)
+        pv = gauss_score_tile<NT>(x, s.prior.tab, g, t);
+      } else {  // IsotropicGauss.score  distr/gauss.py:764-766
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = feat_live<NT>(t, r, 4 * g, s.d) ? (a.iso_loc - x[t][r]) * a.inv_iso_var : 0.0f;
+      }
+      f32x4 bt, bt2 = zero;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float uv = o[0][r];
@@ -154,9 +185,19 @@ SD_INLINE void cmcd_eval(const CmcdArgs& a, const f32x4 (&x)[NT], int ki, float 
           uv = uv + v;
         }
         o[0][r] = uv;
+        float bv = ts[t][r] * w_t + pv[r] * w_1mt;
+        bv = bv * hg2;
+        if (clip_b) bv = clampf(bv, s.cmcd_clip);
+        bt[r] = bv;
+        if constexpr (TWO) {
+          float b2v = ts[t][r] * w2_t + pv[r] * w2_1mt;
+          b2v = b2v * hg2;
+          if (clip_b) b2v = clampf(b2v, s.cmcd_clip);
+          bt2[r] = b2v;
+        }
       }
+      sink(t, o[0], bt, TWO ? bt2 : bt);
     }
-    u[t] = o[0];
   }
 }
 
@@ -201,12 +242,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
     constexpr float sgn = EUBO ? -1.0f : 1.0f;
     f32x4 w_s[NT];
     if (s.N > 0) {
-      f32x4 u0[NT], b0[NT];
-      cmcd_eval<NT, TGT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, ns, lane, u0, b0, b0);
+      cmcd_eval<NT, TGT>(a, x, 0, s.coef[4], s.coef[5], lds, bias, ns, lane, 0.0f, 0.0f, [&](int t, const f32x4& u0, const f32x4& b0, const f32x4&) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w_s[t][r] = b0[t][r] * inv_g + sgn * u0[t][r];
+        for (int r = 0; r < 4; ++r) w_s[t][r] = b0[r] * inv_g + sgn * u0[r];
+      });
     }
 
     for (int k = 0; k < s.N; ++k) {
@@ -217,6 +256,11 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
       // the step loop, runs out of scalar registers and spills them to VGPR lanes -- one v_readlane + wait states per key and use
       uint32_t key_lo = s.seed_lo, key_hi = s.seed_hi;
       asm volatile("" : "+s"(key_lo), "+s"(key_hi));
+      // d > 64, same reason for the per-lane part of every address (LDS images beyond the 64 KiB immediate range, bias rows, tables): left
+      // loop-invariant, ~60 of them are computed once ahead of the step loop and parked in scratch; derived from a value the compiler
+      // cannot see through, they are one add next to their use
+      int lane_k = lane;
+      if constexpr (NT > 4) asm volatile("" : "+v"(lane_k));
       // y = x + (b_s + u_s g) dt + g db ,  db = sqrt(dt) z      (losses/oc.py:722-724; :800-802 with -u for the noising loop)
       f32x4 db[NT];
 #pragma unroll
@@ -235,25 +279,30 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_simulate_cmcd(cons
       }
       // cost = (b_s + b_t)/g + u_s - u_t ;  rnd += 0.5 |cost|^2 dt + <cost, db>   (losses/oc.py:737-742; subtracted at :815-818)
       float c2 = 0.0f, cdb = 0.0f;
-      {
-        f32x4 u_t[NT], b_t[NT], b_n[EUBO ? NT : 1];
-        if constexpr (EUBO) {  // weights of t (cols 6,7 of the row) for the cost, of s (cols 4,5 of the NEXT row) for the next move
-          const float* cn = cf + SDENG_NCOEF;
-          cmcd_eval<NT, TGT, true>(a, x, k + 1, cf[6], cf[7], lds, bias, ns, lane, u_t, b_t, b_n, cn[4], cn[5]);
-        } else {
-          cmcd_eval<NT, TGT>(a, x, k + 1, cf[6], cf[7], lds, bias, ns, lane, u_t, b_t, b_t);
+      auto fold_tile = [&](int t, const f32x4& u_t, const f32x4& b_t, const f32x4& b_n) __attribute__((always_inline)) {  // (t: compile-time index of an unrolled loop)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bg = b_t[r] * inv_g;
+          const float c = w_s[t][r] + (bg - sgn * u_t[r]);
+          c2 = __builtin_fmaf(c, c, c2);
+          cdb = __builtin_fmaf(c, db[t][r], cdb);
+          if constexpr (EUBO) w_s[t][r] = b_n[r] * inv_g - u_t[r];
+          else w_s[t][r] = bg + u_t[r];
         }
+      };
+      // EUBO: weights of t (cols 6,7 of the row) for the cost, of s (cols 4,5 of the NEXT row) for the next move
+      const float wn_t = EUBO ? cf[SDENG_NCOEF + 4] : 0.0f, wn_1mt = EUBO ? cf[SDENG_NCOEF + 5] : 0.0f;
+      if constexpr (NT <= 4) {  // all tiles of (u_t, b_t) first, then the sums (the schedule the d <= 64 kernels were tuned with)
+        f32x4 u_t[NT], b_t[NT], b_n[NT];
+        cmcd_eval<NT, TGT, EUBO>(a, x, k + 1, cf[6], cf[7], lds, bias, ns, lane_k, wn_t, wn_1mt, [&](int t, const f32x4& u, const f32x4& b, const f32x4& bn) __attribute__((always_inline)) {
+          u_t[t] = u;
+          b_t[t] = b;
+          b_n[t] = bn;
+        });
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float bg = b_t[t][r] * inv_g;
-            const float c = w_s[t][r] + (bg - sgn * u_t[t][r]);
-            c2 = __builtin_fmaf(c, c, c2);
-            cdb = __builtin_fmaf(c, db[t][r], cdb);
-            if constexpr (EUBO) w_s[t][r] = b_n[t][r] * inv_g - u_t[t][r];
-            else w_s[t][r] = bg + u_t[t][r];
-          }
+        for (int t = 0; t < NT; ++t) fold_tile(t, u_t[t], b_t[t], b_n[t]);
+      } else {  // d > 64: each tile is folded into the sums as the output layer delivers it (no u[NT], b[NT] arrays: they spilled)
+        cmcd_eval<NT, TGT, EUBO>(a, x, k + 1, cf[6], cf[7], lds, bias, ns, lane_k, wn_t, wn_1mt, fold_tile);
       }
       __builtin_amdgcn_s_setprio(0);  // noise and move of the next step at the lowest level (three levels: 6.49 -> 6.39 ms against two)
       c2 = group_sum(c2);

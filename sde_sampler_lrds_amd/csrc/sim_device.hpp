@@ -184,6 +184,36 @@ SD_INLINE void dense_pre(const f16x8 (&xh)[KB], const f16x8 (&xl)[KB], f32x4 (&o
     for (int to = 0; to < TO; ++to) mx[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[to], xh[kb], mx[to], 0, 0, 0);
   }
 }
+// The same products with the A operands read from a GLOBAL-memory image (prior precision of the CMCD kernels, ...) through a buffer
+// descriptor: a buffer load's address is descriptor base (SGPRs) + scalar offset + ONE 32-bit per-lane offset, so there is no per-lane
+// 64-bit address per (tile, k-block) for the compiler to hoist out of the step loop -- it did that for all 2 * KB * NT of them with plain
+// pointers (2 VGPRs each, every one spilled: 450-840 B of scratch per lane in the d = 128 CMCD kernels).  Out-of-range reads return 0.
+SD_INLINE __amdgpu_buffer_rsrc_t image_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, static_cast<int>(bytes), 0x00020000);
+}
+template <int KB, int TO>
+SD_INLINE void dense_pre_buf(const f16x8 (&xh)[KB], const f16x8 (&xl)[KB], f32x4 (&out)[TO], f32x4 (&mx)[TO], __amdgpu_buffer_rsrc_t img,
+                             uint32_t tile_bytes, int lane) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int voff = lane * 16;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    f16x8 ah[TO], al[TO];
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+      const u32x4 vh = __builtin_amdgcn_raw_buffer_load_b128(img, voff, static_cast<int>(tile_bytes) + ((to * KB + kb) * 2 + 0) * 1024, 0);
+      const u32x4 vl = __builtin_amdgcn_raw_buffer_load_b128(img, voff, static_cast<int>(tile_bytes) + ((to * KB + kb) * 2 + 1) * 1024, 0);
+      ah[to] = __builtin_bit_cast(f16x8, vh);
+      al[to] = __builtin_bit_cast(f16x8, vl);
+    }
+#pragma unroll
+    for (int to = 0; to < TO; ++to) out[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[to], xh[kb], out[to], 0, 0, 0);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) mx[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[to], xl[kb], mx[to], 0, 0, 0);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) mx[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[to], xh[kb], mx[to], 0, 0, 0);
+  }
+}
 template <int TO>
 SD_INLINE void fold_lo(f32x4 (&out)[TO], const f32x4 (&mx)[TO]) {
 #pragma unroll

@@ -114,6 +114,11 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
     }
   }
   __syncthreads();
+#ifdef SD_STAGGER  // A/B builds only: the second wave of each SIMD starts SD_STAGGER x 64 x 127 cycles late (~half a step at 2)
+  if constexpr (REF != RF_GMM_BIG && REF != RF_GMM_FULL && REF != RF_GMM_MM)  // (the shared-table kernels meet at barriers every step)
+    if (wave >= W / 2)
+      for (int i = 0; i < SD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 #ifdef SD_DBG_PRIO_HI47  // DESIGN 4a experiments: which wave of a SIMD is the victim of the packed-fp32 corruption?
   if (wave >= 4) __builtin_amdgcn_s_setprio(3);
 #endif
