@@ -110,6 +110,11 @@ extern "C" {
 #define SDENG_DIST_LOGREG 5     /* distr/logistic_regression.py:11-92 + autograd score distr/base.py:146-154 */
 #define SDENG_DIST_GAUSS_FULL 6 /* distr/gauss.py:632-717  GaussFull (MultivariateNormal)                   */
 #define SDENG_DIST_RINGS 7      /* distr/rings.py:38-109   2-D rings: radial Gaussian mixture x uniform angle     */
+#define SDENG_DIST_GMM_FULL 8   /* distr/gauss.py:310-520  GMMFull / TwoModesFull (full covariances), as the TARGET of a Score / Lerp /
+                                   CancelDrift control only (score_mog_full :110-121 inside the step loop): loc [k,d], scale = eigenvalues
+                                   [k,d] and aux = eigenvectors [k,d,d] (row-major, columns = vectors) of each covariance, w [k].  Forward
+                                   forms without a reference drift (PIS / DDS / DIS); its log-density is not evaluated here (no
+                                   FLAG_TERM_TARGET with it): SDENG_E_UNSUPPORTED otherwise. */
 
 typedef struct sdeng_dist {
   int32_t kind;      /* SDENG_DIST_*                                                              */

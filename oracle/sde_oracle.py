@@ -355,6 +355,17 @@ class GMMFullCov:
         return torch.logsumexp(torch.log(self.w).unsqueeze(0) + lp, dim=-1, keepdim=True)
 
 
+class GMMFullTarget(GMMFullPrec):
+    """distr/gauss.py:310-365 GMMFull(cov=...) as a TARGET: the constructor inverts the covariances once (fp32 ``torch.linalg.inv`` /
+    ``torch.logdet``, :327-333) and both the log-density and ``score`` (:362-365, score_mog_full :110-121) use the precision form."""
+
+    def __init__(self, loc, cov, weights):
+        super().__init__(loc, torch.linalg.inv(cov), torch.logdet(cov), weights)
+
+    def score(self, x):
+        return mog_score_full_prec(x, self.w, self.loc, self.prec, self.log_det)
+
+
 def gauss_score(x, mean, var):
     """distr/gauss.py:124-126."""
     return -(x - mean) / var

@@ -14,7 +14,7 @@ NCOEF = 16
 FORM_LIN, FORM_EM, FORM_CMCD, FORM_EUBO, FORM_CMCD_EUBO = 0, 1, 2, 3, 4
 FLAG_ITO, FLAG_INIT_LOGP, FLAG_TERM_REF, FLAG_TERM_TARGET, FLAG_SPLIT_TILES, FLAG_REMOVE_REF, FLAG_REUSE_PACK = 1, 2, 4, 8, 16, 32, 64
 SPLIT_TILES_MAX_B = 8192  # SDENG_FLAG_SPLIT_TILES is honoured up to this batch size (sdeng.h, sdeng_api.hip split_eligible)
-DIST_NONE, DIST_GMM_DIAG, DIST_GAUSS_DIAG, DIST_ISO_GAUSS, DIST_PHI4, DIST_LOGREG, DIST_GAUSS_FULL, DIST_RINGS = range(8)
+DIST_NONE, DIST_GMM_DIAG, DIST_GAUSS_DIAG, DIST_ISO_GAUSS, DIST_PHI4, DIST_LOGREG, DIST_GAUSS_FULL, DIST_RINGS, DIST_GMM_FULL = range(9)
 CTRL_CLIPPED, CTRL_SCORE, CTRL_LERP, CTRL_NONE, CTRL_CANCEL_DRIFT = 0, 1, 2, 3, 4
 REF_NONE, REF_GAUSS_DIAG, REF_GMM_DIAG, REF_GMM_FULL = 0, 1, 2, 3
 

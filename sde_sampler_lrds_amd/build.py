@@ -62,6 +62,10 @@ def sources():
         path = os.path.join(GEN, f"sim_{dt}_4_0.hip")
         _write_if_changed(path, '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, 4, 0, {fm})\n" for fm in FORMS + (3,)))
         srcs.append(path)
+    for dt in DTS_FULL:  # full-covariance mixture TARGET of a score control, held in the reference slot (REF = 4, SC = 4): forward forms
+        path = os.path.join(GEN, f"sim_{dt}_4_4.hip")
+        _write_if_changed(path, '#include "../sim_kernel.hpp"\n' + "".join(f"SD_DEFINE_SIM({dt}, 4, 4, {fm})\n" for fm in FORMS))
+        srcs.append(path)
     for dt in (5, 6, 7, 8):  # low-latency small-batch kernels (split_kernel.hpp): a tile's features over four waves, d > 64
         path = os.path.join(GEN, f"split_{dt}.hip")
         _write_if_changed(path, '#include "../split_kernel.hpp"\n' + f"SD_DEFINE_SPLIT({dt})\n")

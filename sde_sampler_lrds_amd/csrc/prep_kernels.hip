@@ -224,9 +224,10 @@ __global__ void __launch_bounds__(256) k_ref_full_tables(RefFullArgs a) {
   __shared__ float invd[128];
   __shared__ float red[256];
   const int k = blockIdx.x / a.K, c = blockIdx.x % a.K;
-  const float S = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 9];
-  const float VA = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 10];
-  const float S2 = a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 11];
+  // coef == nullptr: the mixture itself at every step (a full-covariance TARGET held in the reference slot, sim_kernel.hpp SC_REFSLOT)
+  const float S = a.coef ? a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 9] : 1.0f;
+  const float VA = a.coef ? a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 10] : 0.0f;
+  const float S2 = a.coef ? a.coef[static_cast<size_t>(k) * SDENG_NCOEF + 11] : 1.0f;
   const int KB = sd_kb(a.NT);
   const int img_floats = a.NT * KB * 512;
   float ls = 0.0f;

@@ -39,7 +39,7 @@ struct RefTabArgs {
 // full-covariance mixture reference (SDENG_REF_GMM_FULL): per step and component the noised precision as an MFMA image
 struct RefFullArgs {
   int K, d, dpad, NT;
-  const float* coef;
+  const float* coef;  // per-step marginal (cols 9..11); nullptr = the mixture itself at every step
   const float *means, *eigvals, *eigvecs, *weights;
   float* images;     // [N][K][NT*KB*512]  split-f16 A-operand image of P = U diag(1/(VA + S2 lambda)) U^T
   float* means_out;  // [N][K][dpad]       S * mean (0 on pad features)

@@ -24,7 +24,7 @@ int sd_launch_logreg_images(const float* X, const float* y, int n, int dw, int N
 int sd_launch_pack_square(const float* P, const float* loc, int d, int NT, float* out, float* loc_pad, hipStream_t s);
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4, RF_GMM_MM = 5 };
-enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };
+enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3, SC_REFSLOT = 4 };
 
 typedef int (*sim_launch_fn)(const SimArgs&, int grid, hipStream_t);
 #define SD_DECLARE_SIM(DT, REF, SC, FORM) int sd_launch_sim_##DT##_##REF##_##SC##_##FORM(const SimArgs& a, int grid, hipStream_t s);
@@ -64,6 +64,12 @@ SD_TILES_FULL(SD_DECL_FULL)
 SD_TILES(SD_DECL_MM)
 #define SD_TAB_MM(DT) {SD_MM_ROW(SD_ENTRY, DT)},
 static const sim_launch_fn kMMTable[8][2] = {SD_TILES(SD_TAB_MM)};
+// full-covariance mixture TARGET of a Score / Lerp / CancelDrift control, held in the reference slot (SC = 4): [tiles - 1][LIN, EM]
+#define SD_FULLSC_ROW(X, DT) X(DT, 4, 4, 0) X(DT, 4, 4, 1)
+#define SD_DECL_FULLSC(DT) SD_FULLSC_ROW(SD_DECLARE_SIM, DT)
+SD_TILES_FULL(SD_DECL_FULLSC)
+static const sim_launch_fn kFullScoreTable[8][2] = {{SD_FULLSC_ROW(SD_ENTRY, 1)}, {SD_FULLSC_ROW(SD_ENTRY, 2)}, {SD_FULLSC_ROW(SD_ENTRY, 3)}, {SD_FULLSC_ROW(SD_ENTRY, 4)},
+                                                    {nullptr, nullptr}, {SD_FULLSC_ROW(SD_ENTRY, 6)}, {nullptr, nullptr}, {SD_FULLSC_ROW(SD_ENTRY, 8)}};
 static const sim_launch_fn kFullTable[8][3] = {{SD_FULL_ROW(SD_ENTRY, 1)}, {SD_FULL_ROW(SD_ENTRY, 2)}, {SD_FULL_ROW(SD_ENTRY, 3)}, {SD_FULL_ROW(SD_ENTRY, 4)},
                                                {nullptr, nullptr, nullptr}, {SD_FULL_ROW(SD_ENTRY, 6)}, {nullptr, nullptr, nullptr}, {SD_FULL_ROW(SD_ENTRY, 8)}};
 #define SD_CTRL_ROW(M, DT) M(DT, 0) M(DT, 1) M(DT, 2)
@@ -186,8 +192,40 @@ static bool make_layout(const sdeng_desc* d, Layout& L) {
   return true;
 }
 
+// A full-covariance mixture as the target of a score control (SDENG_DIST_GMM_FULL) is evaluated by the machinery of the full-covariance
+// REFERENCE: the descriptor is rewritten so that the mixture occupies the (empty) reference slot -- layout, table kernel and the
+// RF_GMM_FULL step loop then need no second copy -- and the caller remembers that the slot feeds the control, not the drift.
+static bool slot_target(const sdeng_desc* d, sdeng_desc& out) {
+  if (!d || d->target.kind != SDENG_DIST_GMM_FULL) return false;
+  out = *d;
+  out.ref.kind = SDENG_REF_GMM_FULL;
+  out.ref.k = d->target.k;
+  out.ref.means_init = d->target.loc;
+  out.ref.vars_init = d->target.scale;
+  out.ref.eigvecs = d->target.aux;
+  out.ref.weights = d->target.w;
+  out.ref.shared_var = 0;
+  memset(&out.target, 0, sizeof(out.target));
+  return true;
+}
+static int check_slot_target(const sdeng_desc* d) {  // d: the caller's descriptor
+  if (d->ref.kind != SDENG_REF_NONE)
+    return fail(SDENG_E_UNSUPPORTED, "full-covariance mixture target of a score control together with a reference drift (ref.kind %d)", d->ref.kind);
+  if (d->net.ctrl_kind != SDENG_CTRL_SCORE && d->net.ctrl_kind != SDENG_CTRL_LERP && d->net.ctrl_kind != SDENG_CTRL_CANCEL_DRIFT)
+    return fail(SDENG_E_UNSUPPORTED, "SDENG_DIST_GMM_FULL is the target of a Score / Lerp / CancelDrift control only (ctrl_kind %d)", d->net.ctrl_kind);
+  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM)
+    return fail(SDENG_E_UNSUPPORTED, "full-covariance mixture target of a score control: forward forms only (form %d)", d->form);
+  if (d->flags & (SDENG_FLAG_TERM_TARGET | SDENG_FLAG_REMOVE_REF))
+    return fail(SDENG_E_UNSUPPORTED, "SDENG_DIST_GMM_FULL: no log-density kernel (FLAG_TERM_TARGET) and no RemoveReferenceCtrl");
+  if (d->target.k < 1 || !d->target.loc || !d->target.scale || !d->target.aux)
+    return fail(SDENG_E_INVALID, "SDENG_DIST_GMM_FULL: null means / eigenvalues / eigenvectors or k < 1");
+  return 0;
+}
+
 extern "C" size_t sdeng_workspace_bytes(const sdeng_desc* desc) {
   Layout L;
+  sdeng_desc ds;
+  if (slot_target(desc, ds)) desc = &ds;
   if (!make_layout(desc, L)) return 0;
   return L.total * sizeof(float);
 }
@@ -432,6 +470,14 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!d) return fail(SDENG_E_INVALID, "null descriptor");
   if (d->abi_version != SDENG_ABI_VERSION) return fail(SDENG_E_INVALID, "ABI version %d, library has %d", d->abi_version, SDENG_ABI_VERSION);
+  sdeng_desc dslot;
+  const bool target_in_slot = d->target.kind == SDENG_DIST_GMM_FULL;
+  if (target_in_slot) {
+    int rcs = check_slot_target(d);
+    if (rcs) return rcs;
+    slot_target(d, dslot);
+    d = &dslot;
+  }
   Layout L;
   if (!make_layout(d, L)) return fail(SDENG_E_INVALID, "bad sizes: B=%d d=%d N=%d (need 1 <= d <= 128)", d->B, d->d, d->N);
   if (d->B == 0) return 0;
@@ -478,8 +524,14 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
   int rc = prepare_net(d, L, ws, DT, a, s, d->N, false, 0.0f);
   if (rc) return rc;
   int sc;
-  rc = score_kind(d, sc);
-  if (rc) return rc;
+  if (target_in_slot) {
+    sc = SC_REFSLOT;
+    if (d->net.ctrl_kind == SDENG_CTRL_LERP && d->prior.kind != SDENG_DIST_ISO_GAUSS)
+      return fail(SDENG_E_UNSUPPORTED, "LerpCtrl needs an IsotropicGauss prior (kind %d given)", d->prior.kind);
+  } else {
+    rc = score_kind(d, sc);
+    if (rc) return rc;
+  }
 
   // reference drift tables
   int rf = RF_NONE;
@@ -540,7 +592,7 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
       return fail(SDENG_E_INVALID, "full-covariance reference: null means / eigenvalues / eigenvectors or k < 1");
     if (d->N > 0) {
       RefFullArgs r;
-      r.K = K; r.d = d->d; r.dpad = dpad; r.NT = DT; r.coef = d->coef;
+      r.K = K; r.d = d->d; r.dpad = dpad; r.NT = DT; r.coef = target_in_slot ? nullptr : d->coef;  // a target does not diffuse
       r.means = d->ref.means_init; r.eigvals = d->ref.vars_init; r.eigvecs = d->ref.eigvecs; r.weights = d->ref.weights;
       r.images = ws + L.ref_tab; r.means_out = ws + L.ref_mean; r.consts = ws + L.ref_consts;
       SD_HIP(sd_launch_ref_full_tables(r, d->N, s));
@@ -607,6 +659,8 @@ extern "C" int sdeng_simulate(const sdeng_desc* d, void* stream) {
     fn = kLogregTable[dt_index(DT)][d->form];
   } else if (rf == RF_GMM_MM) {
     fn = kMMTable[dt_index(DT)][d->form];
+  } else if (rf == RF_GMM_FULL && sc == SC_REFSLOT) {
+    fn = kFullScoreTable[dt_index(DT)][d->form];
   } else if (rf == RF_GMM_FULL) {
     if (sc != SC_NONE) return fail(SDENG_E_UNSUPPORTED, "full-covariance reference together with a Score/LerpCtrl");
     fn = kFullTable[dt_index(DT)][d->form];

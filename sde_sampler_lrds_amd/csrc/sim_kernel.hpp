@@ -13,7 +13,11 @@
 #include "sim_device.hpp"
 
 enum { RF_NONE = 0, RF_GAUSS = 1, RF_GMM = 2, RF_GMM_BIG = 3, RF_GMM_FULL = 4, RF_GMM_MM = 5 };  // GMM: K <= SD_KREG (responsibilities in registers); FULL: full covariances; MM: shared-variance mixture on the matrix pipe
-enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3 };  // LOGREG: no reference table slots, d <= 64 (LDS)
+enum { SC_NONE = 0, SC_GMM = 1, SC_PHI4 = 2, SC_LOGREG = 3, SC_REFSLOT = 4 };  // LOGREG: no reference table slots, d <= 64 (LDS)
+// SC_REFSLOT: the target of the Score / Lerp / CancelDrift control is a FULL-covariance mixture (GMMFull / TwoModesFull, distr/gauss.py:310-520,
+// score_mog_full :110-121).  Its precision images sit in the reference slot (REF = RF_GMM_FULL, tables of the static marginal s = 1,
+// sigma^2 = 0 written N times by k_ref_full_tables), the mixture score the slot produces feeds the control, and the SDE has no reference
+// drift (PIS / DDS / DIS with a target-informed control): every reference term of the tail compiles out.
 
 // score part of the generative control (added to clip(net)):
 //   ScoreCtrl (models/reparam.py:112-117):  scale*clip(score_pi(x)) * s_theta(t)
@@ -129,6 +133,8 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
   if (wave >= 4) return;
 #endif
   static_assert(SC != SC_LOGREG || (REF == RF_NONE && NT <= 4), "in-loop logistic-regression score: no reference, d <= 64");
+  static_assert(SC != SC_REFSLOT || (REF == RF_GMM_FULL && FORM != SDENG_FORM_EUBO), "full-covariance target score: lives in the reference slot, forward forms");
+  constexpr bool has_ref = REF != RF_NONE && SC != SC_REFSLOT;  // is there a reference DRIFT (the slot may hold the control's target instead)
   const float* bias = a.wpack + sd_off_bias(NT);
   const NetScale ns = load_net_scale(bias, NT);
 #ifdef SD_NO_RANGE_GUARD  // A/B builds only (tools/variant_lib.sh): the step loop without the range guard of DESIGN 4b
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       float hid_rs = 1.0f;
 
       // ---- scores at the OLD state: target score inside the control, reference drift ----
-      f32x4 ts[SC != SC_NONE ? NT : 1];
+      f32x4 ts[(SC != SC_NONE && SC != SC_REFSLOT) ? NT : 1];
       if constexpr (SC == SC_GMM) {
         if (NT == 1 && a.target.kind == SDENG_DIST_RINGS) ts[0] = rings_score(x[0], a.target, g);
         else gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
@@ -466,7 +472,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       // ---- per pair of output tiles: out_layer (MFMA) -> clip -> cost -> noise -> integrator -> Ito term ----
       float su2 = 0.0f, suz = 0.0f, sux = 0.0f;
       // (NT odd: pairs, then the last tile alone -- `t0` is a constant after unrolling, the dead branch goes away)
-      constexpr bool can_remove = SC != SC_NONE && REF != RF_NONE && !eubo;
+      constexpr bool can_remove = SC != SC_NONE && has_ref && !eubo;
       auto ref_tile = [&](int t) __attribute__((always_inline)) -> f32x4 {  // reference score of feature tile t
         f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};
 #ifdef SD_DBG_NOREF
@@ -531,7 +537,8 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
           const int t = t0 + o;
-          if constexpr (SC != SC_NONE) add_ctrl_score_tile(a, u[o], ts[t], x[t], st, score_gain, lerp_w, t, 4 * g, d_dyn);
+          if constexpr (SC == SC_REFSLOT) add_ctrl_score_tile(a, u[o], rs[t], x[t], st, score_gain, lerp_w, t, 4 * g, d_dyn);
+          else if constexpr (SC != SC_NONE) add_ctrl_score_tile(a, u[o], ts[t], x[t], st, score_gain, lerp_w, t, 4 * g, d_dyn);
           f32x4 rq = {0.0f, 0.0f, 0.0f, 0.0f};  // reference score of this tile
           if constexpr (can_remove) {
             // RemoveReferenceCtrl (models/reparam.py:46-64, use_rescaling = False): the control is ctrl - ref_score; the reference score of
@@ -548,7 +555,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
             if constexpr (!eubo) su2 = __builtin_fmaf(uv, uv, su2);
           }
           const f32x4 z = noise_tile(t);  // EUBO: the same counters as in the noising phase above, regenerated
-          if constexpr (!can_remove) rq = ref_tile(t);
+          if constexpr (!can_remove && has_ref) rq = ref_tile(t);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float xv = x[t][r], uv = u[o][r];
@@ -558,7 +565,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
               suz = __builtin_fmaf(uv, z[r], suz);
             } else if constexpr (lin) {  // eq/sdes.py:535-538: ret = c1*x + c2*(ref + u); ret += c3*z
               float sc = uv;
-              if constexpr (REF != RF_NONE) sc = rq[r] + uv;
+              if constexpr (has_ref) sc = rq[r] + uv;
               // fused multiply-adds (round 2): one rounding per term less than the reference's separate torch ops -- within an ulp
               // of them per step, like the drift-net products -- and two instructions fewer per element
               x[t][r] = __builtin_fmaf(c3, z[r], __builtin_fmaf(c2, sc, c1 * xv));
@@ -567,7 +574,7 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
               // x + (c1 x + c3 ref + c2 u) dt + c2 sqrt(dt) z with the per-step products formed once (e1 = 1 + c1 dt, e2 = c2 dt,
               // e3 = c3 dt, e4 = c2 sqrt(dt)): three fused instructions per element; <u, db> = sqrt(dt) <u, z> is scaled after the sum
               float acc = e1 * xv;
-              if constexpr (REF != RF_NONE) acc = __builtin_fmaf(e3, rq[r], acc);
+              if constexpr (has_ref) acc = __builtin_fmaf(e3, rq[r], acc);
               x[t][r] = __builtin_fmaf(e4, z[r], __builtin_fmaf(e2, uv, acc));
               suz = __builtin_fmaf(uv, z[r], suz);
             }

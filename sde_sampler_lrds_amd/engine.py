@@ -43,8 +43,9 @@ def _self_of(fn):
 # ------------------------------------------------------------------------------------------------
 # distributions
 # ------------------------------------------------------------------------------------------------
-def dist_desc(obj, device, keep, clip=None) -> L.Dist:
-    """Distribution object -> sdeng_dist (distr/*.py parameters)."""
+def dist_desc(obj, device, keep, clip=None, score_only=False) -> L.Dist:
+    """Distribution object -> sdeng_dist (distr/*.py parameters).  ``score_only``: the descriptor is the target of a Score / Lerp /
+    CancelDrift control and only its score is evaluated -- the one use a full-covariance mixture has a kernel for."""
     ds = L.Dist()
     ds.clip = float(clip) if clip else 0.0
     if obj is None:
@@ -112,6 +113,23 @@ def dist_desc(obj, device, keep, clip=None) -> L.Dist:
         ds.loc = _dev_f32(obj.radiuses, device, keep)
         ds.w = _dev_f32(obj.radius_dist.mixture_distribution.probs, device, keep)
         ds.p0 = float(obj.radius_dist.component_distribution.scale.reshape(-1)[0])
+        return ds
+    if n in ("GMMFull", "TwoModesFull") and score_only:
+        # score_mog_full inside the step loop (distr/gauss.py:110-121): the kernel takes each covariance in its eigen form, decomposed
+        # once per parameter version in fp64 (the reference inverts the covariances once, in fp32, at construction)
+        cov = getattr(obj, "cov", None)
+        if cov is not None:
+            eig = _EIGH.get(cov, lambda v: torch.linalg.eigh(v.detach().double()))
+            evals, evecs = eig[0].float(), eig[1].float()
+        else:
+            eig = _EIGH.get(obj.prec, lambda v: torch.linalg.eigh(v.detach().double()))
+            evals, evecs = (1.0 / eig[0]).float(), eig[1].float()
+        ds.kind = L.DIST_GMM_FULL
+        ds.k = int(obj.loc.shape[0])
+        ds.loc = _dev_f32(obj.loc, device, keep)
+        ds.scale = _dev_f32(evals, device, keep)
+        ds.w = _dev_f32(obj.mixture_weights, device, keep)
+        ds.aux = _dev_f32(evecs, device, keep)
         return ds
     raise UnsupportedByEngine(f"no HIP log-density/score for distribution {n}")
 

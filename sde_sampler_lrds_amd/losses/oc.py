@@ -458,7 +458,7 @@ class BaseOCLoss:
         if res is None and terminal_unnorm_log_prob is not None:
             late.append((-1.0, terminal_unnorm_log_prob))
             if ctrl_tgt is not None:
-                desc.target = E.dist_desc(ctrl_tgt, device, keep)
+                desc.target = E.dist_desc(ctrl_tgt, device, keep, score_only=True)
         if reference_log_prob is not None:
             rr = E.resolve_logp(reference_log_prob)
             ok = False
@@ -506,6 +506,9 @@ class BaseOCLoss:
                                             "reference score it evaluates for the drift)")
             desc.flags |= L.FLAG_REMOVE_REF
         late = self._terminal(desc, keep, device, terminal_unnorm_log_prob, reference_log_prob)
+        if desc.target.kind == L.DIST_GMM_FULL and (ref[0] != "none" or form == L.FORM_EUBO):
+            raise E.UnsupportedByEngine("a full-covariance mixture target inside a Score / Lerp / CancelDrift control is evaluated in the kernel's "
+                                        "reference slot: forward passes of the solvers without a reference drift (PIS / DDS / DIS) only")
         _, lerp_prior = E.ctrl_target(ctrl)
         rnd0 = None
         if initial_log_prob is not None:

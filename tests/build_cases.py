@@ -6,7 +6,7 @@ from __future__ import annotations
 import torch
 
 
-from sde_sampler_lrds_amd.distr.gauss import GMM, Gauss, GaussFull, IsotropicGauss
+from sde_sampler_lrds_amd.distr.gauss import GMM, GMMFull, Gauss, GaussFull, IsotropicGauss
 from sde_sampler_lrds_amd.distr.logistic_regression import LogisticRegression
 from sde_sampler_lrds_amd.distr.phi_four import PhiFour
 from sde_sampler_lrds_amd.distr.rings import Rings
@@ -75,10 +75,23 @@ def build(c, device):
             mod.to(device)
         loss = oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
         out.update(loss=loss, args=(target.unnorm_log_prob, refd.log_prob), kwargs={})
-    elif kind in ("dds", "dds_rings"):
+    elif kind == "pis_full":
+        sde = ScaledBM(diff_coeff=m["diff_coeff"], terminal_t=m["T"])
+        target = GMMFull(dim=d, loc=c["tgt_loc"], cov=c["tgt_cov"], mixture_weights=c["tgt_w"].clone())
+        ctrl = ScoreCtrl(base_model=_mlp(d), score_model=_score_model(), target_score=target.score, detach_score=False,
+                         clip_score=m["clip_score"], clip_model=m["clip_model"], scale_score=m["scale_score"])
+        ctrl.load_state_dict(c.params("ctrl."))
+        refd = Gauss(dim=d, loc=c["ref_loc"], scale=c["ref_scale"])
+        for mod in (sde, target, ctrl, refd):
+            mod.to(device)
+        loss = oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+        out.update(loss=loss, args=(target.unnorm_log_prob, refd.log_prob), kwargs={})
+    elif kind in ("dds", "dds_rings", "dds_full"):
         if kind == "dds_rings":
             target = Rings(dim=2, lower_rad=m["lower_rad"], upper_rad=m["upper_rad"], num_rad=m["num_rad"], scale=m["scale"],
                            n_reference_samples=10)
+        elif kind == "dds_full":
+            target = GMMFull(dim=d, loc=c["tgt_loc"], cov=c["tgt_cov"], mixture_weights=c["tgt_w"].clone())
         else:
             target = GMM(dim=d, loc=c["tgt_loc"], scale=c["tgt_scale"], mixture_weights=c["tgt_w"].clone())
         prior = IsotropicGauss(dim=d, scale=m["sigma"])

@@ -481,12 +481,52 @@ def case_pis_phi4(name, d, B, N, seed, dt):
     finish(name, meta, arrays, res, draws)
 
 
-def case_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0, rings=False):
+def _full_cov_target(d, K, seed):
+    """GMMFull / TwoModesFull target (distr/gauss.py:310-520).  K = 0: the reference's own TwoModesFull(dim=d) (conf/target/two_modes_full.yaml);
+    K > 0: a GMMFull with K random means and well-conditioned random covariances."""
+    if K == 0:
+        return r_gauss.TwoModesFull(dim=d, a=1.0, ill_conditioned="medium", n_reference_samples=10)
+    g = torch.Generator().manual_seed(seed + 1000)
+    loc = 1.5 * torch.randn(K, d, generator=g)
+    a = torch.randn(K, d, d, generator=g) / math.sqrt(d)
+    cov = 0.6 * torch.matmul(a, a.transpose(1, 2)) + 0.4 * torch.eye(d)
+    return r_gauss.GMMFull(dim=d, loc=loc, cov=cov, mixture_weights=torch.rand(K, generator=g) + 0.5, n_reference_samples=10)
+
+
+def case_pis_full(name, d, K, B, N, seed, dt):
+    """PIS (EMReferenceSDELoss without a reference drift, solver/oc.py:358-378) with a target-informed ScoreCtrl on a FULL-covariance
+    mixture target: score_mog_full (distr/gauss.py:110-121) inside the step loop."""
+    torch.manual_seed(seed)
+    g, Tstar = math.sqrt(0.2), N * dt
+    sde = r_sdes.ScaledBM(diff_coeff=g, terminal_t=Tstar)
+    target = _full_cov_target(d, K, seed)
+    prior = r_delta.Delta(dim=d)
+    ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.02),
+                           target_score=target.score, detach_score=False, clip_score=1e4, clip_model=1e4,
+                           scale_score=1.0)
+    ref_distr = sde.marginal_distr(t=sde.terminal_t, x_init=prior.loc)
+    loss = r_oc.EMReferenceSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    ts = torch.linspace(0.0, N * dt, N + 1)
+    x0 = prior.sample((B,))
+    res, draws = run_with_replay(seed, lambda: loss.eval(ts, x0.clone(), target.unnorm_log_prob, ref_distr.log_prob,
+                                                         compute_weights=True, return_traj=True, use_ema=False))
+    (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
+        ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=ref_distr.log_prob))
+    meta = dict(kind="pis_full", d=d, K=int(target.loc.shape[0]), B=B, N=N, seed=seed, diff_coeff=g, T=Tstar, clip_model=1e4, clip_score=1e4,
+                scale_score=1.0)
+    arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], ref_loc=ref_distr.loc, ref_scale=ref_distr.scale,
+                  tgt_loc=target.loc, tgt_cov=target.cov, tgt_w=target.mixture_weights, **pack_params("ctrl.", sd(ctrl)))
+    finish(name, meta, arrays, res, draws)
+
+
+def case_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0, rings=False, full=False):
     """DDS on TwoModes or Rings (conf/solver/dds.yaml, conf/loss/exponential_sde.yaml, conf/target/rings.yaml,
     solver/oc.py:438-452)."""
     torch.manual_seed(seed)
     if rings:
         target = r_rings.Rings(dim=2, n_reference_samples=10)
+    elif full:
+        target = _full_cov_target(d, 0, seed)
     else:
         target = r_gauss.TwoModes(dim=d, a=1.0, ill_conditioned="not", n_reference_samples=10)
     prior = r_gauss.IsotropicGauss(dim=d, scale=sigma)
@@ -501,11 +541,13 @@ def case_dds(name, d, B, seed, dt=0.4, end=6.4, sigma=1.0, rings=False):
     (x_n, rnd, _), _ = run_with_replay(seed, lambda: loss.simulate(
         ts, x0.clone(), terminal_unnorm_log_prob=target.unnorm_log_prob, reference_log_prob=prior.log_prob,
         compute_ito_int=True))
-    meta = dict(kind="dds_rings" if rings else "dds", d=d, B=B, N=len(ts) - 1, seed=seed, alpha=1.0, sigma=sigma, clip_model=1e4,
-                clip_score=1e4, scale_score=1.0, dt=dt, end=end)
+    meta = dict(kind="dds_rings" if rings else ("dds_full" if full else "dds"), d=d, B=B, N=len(ts) - 1, seed=seed, alpha=1.0, sigma=sigma,
+                clip_model=1e4, clip_score=1e4, scale_score=1.0, dt=dt, end=end)
     if rings:
         meta.update(lower_rad=1.0, upper_rad=5.0, num_rad=3, scale=0.1)
         tgt_arrays = dict(rings_rad=target.radiuses, rings_w=target.radius_dist.mixture_distribution.probs)
+    elif full:
+        tgt_arrays = dict(tgt_loc=target.loc, tgt_cov=target.cov, tgt_w=target.mixture_weights)
     else:
         tgt_arrays = dict(tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
     arrays = dict(ts=ts, x0=x0, rnd=rnd, xs_last2=res.xs[-2:], **tgt_arrays, **pack_params("ctrl.", sd(ctrl)))
@@ -956,6 +998,10 @@ CASES = {
     # config 1 (TwoModes d=2, DDS) and the Rings target on the same solver
     "dds_two_modes_d2": lambda n: case_dds(n, d=2, B=128, seed=31),
     "dds_rings_d2": lambda n: case_dds(n, d=2, B=128, seed=32, rings=True),
+    # target-informed controls on FULL-covariance mixture targets (score_mog_full in the step loop): the reference's TwoModesFull, a GMMFull
+    "dds_two_modes_full_d5": lambda n: case_dds(n, d=5, B=128, seed=33, full=True),
+    "pis_two_modes_full_d20": lambda n: case_pis_full(n, d=20, K=0, B=64, N=40, seed=34, dt=0.05),
+    "pis_gmm_full_d128_k3": lambda n: case_pis_full(n, d=128, K=3, B=32, N=32, seed=35, dt=0.05),
     # config 4 (logreg d=61, CMCD), at the real step size 1/256
     "cmcd_logreg_d61": lambda n: case_cmcd_logreg(n, B=64, N=16, seed=41, dt=1.0 / 256),
     "cmcd_gmm_iso_d16": lambda n: case_cmcd_gmm(n, d=16, K=4, B=64, N=32, seed=42, prior_kind="iso"),

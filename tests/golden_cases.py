@@ -20,6 +20,7 @@ SIM_CASES = [
     "rds_ei_pbm_default_d16", "pis_em_phi4_d100", "dds_two_modes_d2", "dds_rings_d2", "cmcd_logreg_d61", "cmcd_gmm_iso_d16", "cmcd_gmm_diag_d40", "cmcd_phi4_d100", "pis_logreg_d61", "dds_logreg_d61", "dis_ei_d8",
     "dis_orig_lerp_d8", "rds_ei_gmm_fullcov_d128_k4", "rds_em_gmm_fullcov_d40_k3", "rds_ei_gmm_eigen_d16_k3",
     "rds_ei_gauss_fullcov_d40", "dis_ei_cancel_drift_d8", "rds_em_remove_ref_d16", "rds_ei_remove_ref_d40",
+    "dds_two_modes_full_d5", "pis_two_modes_full_d20", "pis_gmm_full_d128_k3",
 ]
 
 
@@ -163,9 +164,18 @@ def run_oracle(c: Case, noise=None, B=None):
                         clip_score=m["clip_score"], scale_score=m["scale_score"])
         refd = orc.GaussDiag(c["ref_loc"], c["ref_scale"])
         out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, None, noise)
-    elif kind in ("dds", "dds_rings"):
+    elif kind == "pis_full":  # PIS with a ScoreCtrl on a full-covariance mixture target
+        sde = orc.ScaledBM(m["diff_coeff"], m["T"])
+        tgt = orc.GMMFullTarget(c["tgt_loc"], c["tgt_cov"], c["tgt_w"])
+        ctrl = orc.Ctrl(c.params("ctrl."), "score", clip_model=m["clip_model"], target_score=tgt.score,
+                        clip_score=m["clip_score"], scale_score=m["scale_score"])
+        refd = orc.GaussDiag(c["ref_loc"], c["ref_scale"])
+        out = orc.simulate_em_ref(ts, x0, ctrl, sde, tgt.logp, refd.logp, None, noise)
+    elif kind in ("dds", "dds_rings", "dds_full"):
         if kind == "dds_rings":
             tgt = orc.Rings(m["lower_rad"], m["upper_rad"], m["num_rad"], m["scale"])
+        elif kind == "dds_full":
+            tgt = orc.GMMFullTarget(c["tgt_loc"], c["tgt_cov"], c["tgt_w"])
         else:
             tgt = orc.GMMDiag(c["tgt_loc"], c["tgt_scale"], c["tgt_w"])
         prior = orc.IsoGauss(m["d"], 0.0, m["sigma"])

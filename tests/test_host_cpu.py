@@ -64,6 +64,12 @@ def test_descriptor_compiles_on_host(name):
     assert ref.kind in (L.REF_NONE, L.REF_GAUSS_DIAG, L.REF_GMM_DIAG, L.REF_GMM_FULL)
     assert (ref.kind == L.REF_GMM_FULL) == ("fullcov" in name or "eigen" in name) and bool(ref.eigvecs) == (ref.kind == L.REF_GMM_FULL)
     tgt = E.resolve_logp(b["args"][0])
+    if "tgt_cov" in c.a:  # full-covariance mixture target: a descriptor for the score inside the control only (terminal cost via torch)
+        with pytest.raises(E.UnsupportedByEngine):
+            E.dist_desc(tgt[0], "cpu", keep)
+        ds = E.dist_desc(tgt[0], "cpu", keep, score_only=True)
+        assert ds.kind == L.DIST_GMM_FULL and ds.k == c["tgt_loc"].shape[0] and ds.aux and ds.scale
+        return
     assert tgt is not None and E.dist_desc(tgt[0], "cpu", keep).kind != L.DIST_NONE
 
 

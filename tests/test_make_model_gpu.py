@@ -44,6 +44,10 @@ def test_make_model_rds_gmm_evaluate(gpu):
     ("vp-ref", "default", "em", "target_informed_langevin_init", "snr", "many_modes", dict(sigma=1.0)),
     ("dis_orig", "default", "em", "target_informed_langevin_init", "uniform", "many_modes", dict(sigma=1.0)),
     ("vp-ref", "default", "ei", "base_zero_init", "uniform", "two_modes_full", dict(sigma=1.0)),  # full-covariance target: terminal cost via torch
+    # ... and inside a target-informed control (score_mog_full in the step loop, the mixture held in the reference slot)
+    ("pis_orig", "default", "em", "target_informed_zero_init", "uniform", "two_modes_full", dict(sigma=0.4472135954999579)),
+    ("dds_orig", "default", "em", "target_informed_zero_init", "uniform", "two_modes_full", dict(sigma=1.0)),
+    ("dis_orig", "default", "em", "target_informed_lerp_tempering", "uniform", "two_modes_full", dict(sigma=1.0)),
     ("cmcd", "default", "em", "target_informed_zero_init", "uniform", "many_modes", dict()),
     ("cmcd", "gaussian", "em", "target_informed_zero_init", "uniform", "many_modes", dict(mean=torch.zeros(8), var=3.0 * torch.ones(8))),
 ])
@@ -63,6 +67,20 @@ def test_make_model_rejects_what_the_reference_rejects(gpu):
     tgt = make_target_details("bracket_two_modes", dim=8)
     with pytest.raises(ValueError, match="Only target_informed_zero_init model is supported."):
         make_model("pis_orig", "default", "lv", "em", "target_informed_langevin_init", "uniform", dict(sigma=0.4472135954999579), tgt, _train(512))
+
+
+@pytest.mark.gpu
+def test_full_covariance_target_limits_are_loud(gpu):
+    """A full-covariance mixture target has a score kernel only inside a control WITHOUT a reference drift (PIS / DDS / DIS); with a
+    reference (the slot is taken), as a stand-alone control evaluation, or in training it raises -- never a silent fallback."""
+    from sde_sampler_lrds_amd import engine as E
+    tgt = make_target_details("two_modes_full", dim=8)
+    model = make_model("vp-ref", "default", "lv", "em", "target_informed_langevin_init", "uniform", dict(sigma=1.0), tgt, _train(256), n_steps=8)
+    with pytest.raises(E.UnsupportedByEngine, match="reference drift"):
+        model.evaluate()
+    pis = make_model("pis_orig", "default", "lv", "em", "target_informed_zero_init", "uniform", dict(sigma=0.4472135954999579), tgt, _train(256), n_steps=8)
+    with pytest.raises(E.UnsupportedByEngine):
+        pis.generative_ctrl(torch.tensor(0.5, device=gpu), torch.zeros(4, 8, device=gpu))
 
 
 @pytest.mark.gpu
