@@ -72,15 +72,18 @@ def test_make_model_rejects_what_the_reference_rejects(gpu):
 @pytest.mark.gpu
 def test_full_covariance_target_limits_are_loud(gpu):
     """A full-covariance mixture target has a score kernel only inside a control WITHOUT a reference drift (PIS / DDS / DIS); with a
-    reference (the slot is taken), as a stand-alone control evaluation, or in training it raises -- never a silent fallback."""
+    reference (the slot is taken) or as a stand-alone HIP control evaluation it raises -- never a silent fallback."""
     from sde_sampler_lrds_amd import engine as E
     tgt = make_target_details("two_modes_full", dim=8)
     model = make_model("vp-ref", "default", "lv", "em", "target_informed_langevin_init", "uniform", dict(sigma=1.0), tgt, _train(256), n_steps=8)
     with pytest.raises(E.UnsupportedByEngine, match="reference drift"):
         model.evaluate()
     pis = make_model("pis_orig", "default", "lv", "em", "target_informed_zero_init", "uniform", dict(sigma=0.4472135954999579), tgt, _train(256), n_steps=8)
-    with pytest.raises(E.UnsupportedByEngine):
-        pis.generative_ctrl(torch.tensor(0.5, device=gpu), torch.zeros(4, 8, device=gpu))
+    from sde_sampler_lrds_amd import _lib as L
+    with pytest.raises((E.UnsupportedByEngine, L.EngineError), match="target kind 8"):  # sdeng_ctrl_forward has no staged-precision path
+        E.ctrl_forward(pis.generative_ctrl, 0.5, torch.zeros(4, 8, device=gpu))
+    u = pis.generative_ctrl(torch.tensor(0.5, device=gpu), torch.zeros(4, 8, device=gpu))  # (the module's own torch forward, as upstream)
+    assert u.shape == (4, 8) and torch.isfinite(u).all()
 
 
 @pytest.mark.gpu
