@@ -294,6 +294,33 @@ int sdeng_ctrl_vjp(const sdeng_desc* desc, int32_t n_times, int32_t rows_per_tim
                    float* a2, float* d0, float* d1, float* d2, float* dout, float* gx, float* u_out, void* stream);
 size_t sdeng_ctrl_vjp_workspace_bytes(int32_t d, int32_t n_times);
 
+/* KL-method training (BaseOCLoss.compute_loss kl branch, losses/oc.py:105-131): the gradient of the mean log-weight through the
+ * trajectory -- what loss.backward() computes by walking the autograd graph of simulate() (losses/oc.py:258-284 EM, :478-502 EI) -- as the
+ * discrete adjoint of the recursion sdeng_simulate integrates, in ONE launch.  The states xs[k] (k = 0 .. N-1, from sdeng_simulate's xs_out)
+ * are constants; per 16 particles the kernel walks k = N-1 .. 0 with the adjoint state lambda in registers:
+ *     cot_k  = alpha_k lambda + w_b (beta_k u_k + gamma_k z_k)        u_k = the control at (coef[k][0], xs[k]), recomputed
+ *     lambda = A_k lambda + C_k H_ref(xs[k]) lambda + J_u^T cot_k     H_ref: Jacobian of the noised reference's score (eq/sdes.py:265-279, 329-345)
+ * (FORM_LIN: alpha = c2, beta = 2 c4, gamma = c5, A = c1, C = c2;  FORM_EM: alpha = c2 c4, beta = c4, gamma = c5, A = 1 + c4 c1, C = c4 c3;
+ * gamma = 0 without SDENG_FLAG_ITO) and writes the per-row arrays of sdeng_ctrl_vjp at row k * B + b: the parameter gradients are the same
+ * six products.  Reads desc->{abi_version, B, d, N, form, flags & ITO, coef, net, ref (NONE / GAUSS_DIAG / GMM_DIAG), target, workspace}.
+ * Controls: ClippedCtrl, and ScoreCtrl (models/reparam.py:63-117; BASELINE config 1, DDS) on a diagonal mixture target (desc->target of kind
+ * GMM_DIAG): u = clip(net) + scale clip(score_pi(x)) s_theta(t); the state gradient gains scale s_theta H_pi(x) (mask cot) (closed-form
+ * Hessian-vector product; skipped with detach_score), and `dst` receives the cotangent of s_theta(t_k) per particle -- the caller sums
+ * it over the particles and back-propagates the N values through the small score model. */
+typedef struct sdeng_adjoint {
+  const float* xs;      /* [N][B][d] states x_0 .. x_{N-1}                                                   */
+  const float* noise;   /* [N][B][d] the normals of the trajectory (sdeng_philox_normal_steps of its seed); required with FLAG_ITO */
+  const float* w;       /* [B] d loss / d rnd_b (1/B on the particles that pass the loss's filter, else 0)   */
+  const float* lam_in;  /* [B][d] lambda_N = d (sum_b w_b terminal(x_N,b)) / d x_N                           */
+  float* lam_out;       /* [B][d] lambda_0, or NULL                                                          */
+  float *a0, *a1, *a2, *d0, *d1, *d2; /* [N*B][64] each, as sdeng_ctrl_vjp                                    */
+  float* dout;          /* [N*B][d]                                                                          */
+  float* dst;           /* [N*B] ScoreCtrl: <cot, scale clip(score_pi)>, the cotangent of s_theta(t_k) per particle; else NULL */
+  int32_t detach_score; /* ScoreCtrl(detach_score=True): the target score is treated as a constant of x     */
+} sdeng_adjoint;
+int sdeng_kl_adjoint(const sdeng_desc* desc, const sdeng_adjoint* adj, void* stream);
+size_t sdeng_kl_adjoint_workspace_bytes(const sdeng_desc* desc);
+
 /* Annealed samplers: n_moves Langevin moves of B chains in ONE launch -- mala_step / ula_step of additions/mcmc.py:77-135,
  * 189-221 with the per-chain step-size heuristic of :55-74 (target_acceptance > 0), as smc_sampler / re_sampler / mcmc_sample apply
  * them move after move (additions/ebm_mle.py:120-160, 340-380; experiments/benchmark_utils.py:300-330).  Density: the geometric path

@@ -45,6 +45,11 @@ class Ref(C.Structure):
                 ("shared_var", C.c_int32), ("reserved", C.c_int32)]
 
 
+class Adjoint(C.Structure):  # sdeng_adjoint (include/sdeng.h)
+    _fields_ = [(n, C.c_void_p) for n in ("xs", "noise", "w", "lam_in", "lam_out", "a0", "a1", "a2", "d0", "d1", "d2", "dout", "dst")] + [
+        ("detach_score", C.c_int32)]
+
+
 class Desc(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("form", C.c_int32), ("flags", C.c_uint32),
                 ("B", C.c_int32), ("d", C.c_int32), ("N", C.c_int32),
@@ -67,7 +72,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsdeng.so
 EXPORTS = ["sdeng_abi_version", "sdeng_last_error", "sdeng_workspace_bytes", "sdeng_simulate", "sdeng_logz",
            "sdeng_logz_workspace_bytes", "sdeng_ctrl_forward", "sdeng_dist_eval", "sdeng_dist_workspace_bytes",
            "sdeng_philox_normal", "sdeng_philox_normal_steps", "sdeng_sample_x0", "sdeng_ctrl_vjp", "sdeng_ctrl_vjp_workspace_bytes",
-           "sdeng_langevin_moves", "sdeng_langevin_moves_workspace_bytes"]
+           "sdeng_langevin_moves", "sdeng_langevin_moves_workspace_bytes", "sdeng_kl_adjoint", "sdeng_kl_adjoint_workspace_bytes"]
 
 
 def lib() -> C.CDLL:
@@ -104,6 +109,10 @@ def lib() -> C.CDLL:
     L.sdeng_sample_x0.argtypes = [C.POINTER(Dist), C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.sdeng_ctrl_vjp.restype = C.c_int
     L.sdeng_ctrl_vjp.argtypes = [C.POINTER(Desc), C.c_int32, C.c_int32] + [C.c_void_p] * 12
+    L.sdeng_kl_adjoint.restype = C.c_int
+    L.sdeng_kl_adjoint.argtypes = [C.POINTER(Desc), C.POINTER(Adjoint), C.c_void_p]
+    L.sdeng_kl_adjoint_workspace_bytes.restype = C.c_size_t
+    L.sdeng_kl_adjoint_workspace_bytes.argtypes = [C.POINTER(Desc)]
     L.sdeng_ctrl_vjp_workspace_bytes.restype = C.c_size_t
     L.sdeng_ctrl_vjp_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     L.sdeng_langevin_moves.restype = C.c_int

@@ -751,6 +751,11 @@ extern "C" int sdeng_ctrl_forward(const sdeng_desc* d, float t_net, float score_
 #define SD_DECLARE_VJP(DT) int sd_launch_vjp_##DT(const VjpArgs& a, int grid, hipStream_t s);
 SD_TILES(SD_DECLARE_VJP)
 typedef int (*vjp_launch_fn)(const VjpArgs&, int grid, hipStream_t);
+#define SD_DECLARE_ADJ(DT) int sd_launch_adjoint_##DT(const AdjArgs& a, int grid, hipStream_t s);
+SD_TILES(SD_DECLARE_ADJ)
+typedef int (*adj_launch_fn)(const AdjArgs&, int grid, hipStream_t);
+#define SD_TAB_ADJ(DT) sd_launch_adjoint_##DT,
+static const adj_launch_fn kAdjTable[8] = {SD_TILES(SD_TAB_ADJ)};
 #define SD_TAB_VJP(DT) sd_launch_vjp_##DT,
 static const vjp_launch_fn kVjpTable[8] = {SD_TILES(SD_TAB_VJP)};
 
@@ -808,6 +813,108 @@ extern "C" int sdeng_ctrl_vjp(const sdeng_desc* d, int32_t n_times, int32_t rows
   a.trash = ws + o_trash;
   a.ntiles = static_cast<int>((M + 15) / 16);
   SD_HIP(kVjpTable[dt_index(DT)](a, grid_for(a.ntiles), s));
+  return 0;
+}
+
+// ---- KL training: the adjoint of the step loop (grad_kernel.hpp k_kl_adjoint) ------------------------------------------------------
+static size_t adjoint_floats(const sdeng_desc* d, int DT, size_t* o_wt, size_t* o_temb, size_t* o_trash, size_t* o_tab, size_t* o_consts,
+                             size_t* o_stheta, size_t* o_target) {
+  size_t o = vjp_floats(DT, d->N, o_wt, o_temb, o_trash);
+  const int K = d->ref.kind == SDENG_REF_NONE ? 0 : (d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k);
+  *o_tab = o; o += align64(static_cast<size_t>(d->N) * K * 2 * 16 * DT);
+  *o_consts = o; o += align64(static_cast<size_t>(d->N) * K * 2 + 1);
+  *o_stheta = o; o += align64(static_cast<size_t>(d->N));
+  *o_target = o; o += dist_floats(d->target, 16 * DT);
+  return o;
+}
+static int check_adjoint(const sdeng_desc* d) {
+  if (!d) return fail(SDENG_E_INVALID, "null descriptor");
+  if (d->abi_version != SDENG_ABI_VERSION) return fail(SDENG_E_INVALID, "ABI version %d, library has %d", d->abi_version, SDENG_ABI_VERSION);
+  if (d->d < 1 || d->d > 128 || d->N < 1 || d->B < 1 || !d->coef) return fail(SDENG_E_INVALID, "bad sizes (1 <= d <= 128, N, B >= 1) or null coef");
+  if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM) return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: forward forms LIN / EM (form %d)", d->form);
+  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && !(d->net.ctrl_kind == SDENG_CTRL_SCORE && d->target.kind == SDENG_DIST_GMM_DIAG))
+    return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: ClippedCtrl, or ScoreCtrl on a diagonal mixture target (ctrl_kind %d, target kind %d)", d->net.ctrl_kind,
+                d->target.kind);
+  if (d->ref.kind != SDENG_REF_NONE && d->ref.kind != SDENG_REF_GAUSS_DIAG && d->ref.kind != SDENG_REF_GMM_DIAG)
+    return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: no reference, or a diagonal Gaussian / mixture reference (ref.kind %d)", d->ref.kind);
+  if (d->ref.kind != SDENG_REF_NONE && ((d->ref.kind == SDENG_REF_GMM_DIAG && d->ref.k < 1) || !d->ref.means_init || !d->ref.vars_init))
+    return fail(SDENG_E_INVALID, "reference: null means/vars or k < 1");
+  if (static_cast<long long>(d->N) * d->B * d->d >= (1ll << 31)) return fail(SDENG_E_UNSUPPORTED, "N * B * d >= 2^31");
+  return check_net(d->net);
+}
+extern "C" size_t sdeng_kl_adjoint_workspace_bytes(const sdeng_desc* d) {
+  if (!d || d->d < 1 || d->d > 128 || d->N < 1) return 0;
+  size_t a, b, c, e, f, g, h;
+  return adjoint_floats(d, tiles_exact(d->d), &a, &b, &c, &e, &f, &g, &h) * sizeof(float);
+}
+extern "C" int sdeng_kl_adjoint(const sdeng_desc* d, const sdeng_adjoint* adj, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = check_adjoint(d);
+  if (rc) return rc;
+  if (!adj || !adj->xs || !adj->w || !adj->lam_in || !adj->a0 || !adj->a1 || !adj->a2 || !adj->d0 || !adj->d1 || !adj->d2 || !adj->dout)
+    return fail(SDENG_E_INVALID, "kl_adjoint: null states / weights / lambda_N / per-row outputs");
+  const bool ito = d->flags & SDENG_FLAG_ITO;
+  if (ito && !adj->noise) return fail(SDENG_E_INVALID, "kl_adjoint: FLAG_ITO needs the normals of the trajectory");
+  const int DT = tiles_exact(d->d), dpad = 16 * DT;
+  size_t o_wt, o_temb, o_trash, o_tab, o_consts, o_stheta, o_target;
+  const size_t need = adjoint_floats(d, DT, &o_wt, &o_temb, &o_trash, &o_tab, &o_consts, &o_stheta, &o_target) * sizeof(float);
+  const bool score = d->net.ctrl_kind == SDENG_CTRL_SCORE;
+  if (score && !adj->dst) return fail(SDENG_E_INVALID, "kl_adjoint: ScoreCtrl needs the dst output");
+  if (!d->workspace || d->workspace_bytes < need) return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, need);
+  float* ws = static_cast<float*>(d->workspace);
+  PackArgs pk;
+  pk.NT = DT; pk.d = d->d;
+  pk.w_in = d->net.w_in; pk.b_in = d->net.b_in; pk.w_h1 = d->net.w_h1; pk.b_h1 = d->net.b_h1;
+  pk.w_h2 = d->net.w_h2; pk.b_h2 = d->net.b_h2; pk.w_out = d->net.w_out; pk.b_out = d->net.b_out;
+  pk.out = ws; pk.transpose = 0; pk.scales = nullptr;
+  SD_HIP(sd_launch_pack(pk, s));
+  PackArgs pt = pk;
+  pt.out = ws + o_wt; pt.transpose = 1; pt.scales = ws + sd_off_scales(DT);
+  SD_HIP(sd_launch_pack(pt, s));
+  TimeEmbedArgs te;
+  te.te = d->net.t_embed; te.coef = d->coef; te.col = 0; te.t_direct = 0; te.t_value = 0.0f; te.clip = 0.0f;
+  te.out = ws + o_temb;
+  SD_HIP(sd_launch_time_embed(te, d->N, s));
+  AdjArgs a;
+  memset(&a, 0, sizeof(a));
+  if (d->ref.kind != SDENG_REF_NONE) {  // the noised reference of every step: (mean, 1/var) tables + logit constants, as the step loop reads them
+    const int K = d->ref.kind == SDENG_REF_GAUSS_DIAG ? 1 : d->ref.k;
+    RefTabArgs r;
+    r.K = K; r.d = d->d; r.dpad = dpad; r.coef = d->coef;
+    r.means = d->ref.means_init; r.vars = d->ref.vars_init; r.weights = d->ref.kind == SDENG_REF_GMM_DIAG ? d->ref.weights : nullptr;
+    r.tab = ws + o_tab; r.consts = ws + o_consts;
+    r.same_var = ws + o_consts + static_cast<size_t>(d->N) * K * 2;
+    r.centred = 0;
+    SD_HIP(sd_launch_ref_tables(r, d->N, s));
+    a.ref_tab = ws + o_tab; a.ref_consts = ws + o_consts; a.ref_k = K;
+    a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
+  }
+  if (score) {
+    a.has_score = 1;
+    if (d->net.score_model.n_hidden > 0) {
+      TimeEmbedArgs sm;
+      sm.te = d->net.score_model; sm.coef = d->coef; sm.col = 0; sm.t_direct = 0; sm.t_value = 0.0f;
+      sm.clip = d->net.clip_model;  // reparam.py:102-110 clips the score model with clip_model
+      sm.out = ws + o_stheta;
+      SD_HIP(sd_launch_time_embed(sm, d->N, s));
+      a.stheta = sm.out;
+    }
+    rc = build_dist(d->target, d->d, dpad, ws + o_target, a.target, s);
+    if (rc) return rc;
+    a.scale_score = d->net.scale_score; a.clip_score = d->net.clip_score;
+    a.score_detached = adj->detach_score ? 1 : 0;
+    a.dst = adj->dst;
+  }
+  VjpArgs& v = a.v;
+  v.M = d->N * d->B; v.B = d->B; v.d = d->d; v.N = d->N;
+  v.x = adj->xs; v.cot = nullptr; v.wpack = ws; v.wpack_t = ws + o_wt; v.temb = ws + o_temb;
+  v.clip_model = d->net.clip_model;
+  v.a0 = adj->a0; v.a1 = adj->a1; v.a2 = adj->a2; v.d0 = adj->d0; v.d1 = adj->d1; v.d2 = adj->d2; v.dout = adj->dout;
+  v.trash = ws + o_trash;
+  a.coef = d->coef; a.noise = ito ? adj->noise : nullptr; a.w = adj->w; a.lam_in = adj->lam_in; a.lam_out = adj->lam_out;
+  a.lin = d->form == SDENG_FORM_LIN ? 1 : 0;
+  a.ntiles_b = (d->B + 15) / 16;
+  SD_HIP(kAdjTable[dt_index(DT)](a, grid_for(a.ntiles_b), s));
   return 0;
 }
 

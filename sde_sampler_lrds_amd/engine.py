@@ -811,6 +811,80 @@ class VjpSession:
         return dict(x=self.x, a0=h[0], a1=h[1], a2=h[2], d0=h[3], d1=h[4], d2=h[5], dout=self.dout, gx=None)
 
 
+def diagonal_reference(kind, utils) -> bool:
+    """No reference drift, or a Gaussian / mixture reference with diagonal covariances (what sdeng_kl_adjoint differentiates in closed form)."""
+    if kind == "none":
+        return True
+    if kind == "gaussian":
+        v = utils["var_init"]
+        return not isinstance(v, tuple) and v.dim() <= 1
+    if kind == "gmm":
+        v = utils["variances_init"]
+        return not isinstance(v, tuple) and v.dim() == 2
+    return False
+
+
+def adjoint_ctrl_ok(ctrl) -> bool:
+    """Does sdeng_kl_adjoint differentiate this control?  ClippedCtrl over a FourierMLP, or a plain ScoreCtrl over one whose target is a
+    diagonal mixture (BASELINE config 1: DDS on TwoModes) and whose score model, if any, is a TimeEmbed."""
+    name = type(ctrl).__name__
+    if type(getattr(ctrl, "base_model", None)).__name__ != "FourierMLP":
+        return False
+    if name == "ClippedCtrl":
+        return True
+    if name != "ScoreCtrl":
+        return False
+    tgt = _self_of(ctrl.target_score)
+    if tgt is None or _name(tgt) not in ("GMM", "TwoModes", "ManyModes", "BracketTwoModes") or getattr(tgt, "mixture_weights", None) is None:
+        return False
+    return ctrl.score_model is None or _name(ctrl.score_model) == "TimeEmbed"
+
+
+def kl_adjoint(ctrl, coef: torch.Tensor, xs: torch.Tensor, z, w: torch.Tensor, lam_n: torch.Tensor, *, lin: bool, ito: bool, ref=("none", {})):
+    """sdeng_kl_adjoint: the whole adjoint recursion of KL training in one launch (ClippedCtrl, or ScoreCtrl on a diagonal mixture target; no
+    reference, or a diagonal Gaussian / mixture reference).  ``coef`` [N,16] on the device, ``xs`` [N,B,d] = x_0 .. x_{N-1}, ``z`` [N,B,d]
+    the trajectory's normals (or None), ``w`` [B,1] = d loss / d rnd, ``lam_n`` [B,d] = lambda_N.  Returns (per-row arrays as ``ctrl_vjp``
+    -- plus ``dst`` [N,B], the per-particle cotangent of s_theta(t_k), for a ScoreCtrl --, lambda_0)."""
+    require_gpu(xs)
+    lib = L.lib()
+    device, keep = xs.device, []
+    N, B, d = xs.shape
+    desc = L.Desc()
+    desc.abi_version = L.ABI_VERSION
+    desc.form = L.FORM_LIN if lin else L.FORM_EM
+    desc.flags = L.FLAG_ITO if ito else 0
+    desc.B, desc.d, desc.N = B, d, N
+    desc.net = net_desc(ctrl, device, keep)
+    if not adjoint_ctrl_ok(ctrl):
+        raise UnsupportedByEngine("kl_adjoint: ClippedCtrl, or ScoreCtrl on a diagonal mixture target")
+    score = desc.net.ctrl_kind == L.CTRL_SCORE
+    if score:
+        desc.target = dist_desc(ctrl_target(ctrl)[0], device, keep)
+    desc.ref = ref_desc(ref[0], ref[1], device, keep)
+    if desc.ref.kind not in (L.REF_NONE, L.REF_GAUSS_DIAG, L.REF_GMM_DIAG):
+        raise UnsupportedByEngine("kl_adjoint: diagonal references only")
+    cf = coef.detach().to(device=device, dtype=torch.float32).contiguous()
+    desc.coef = cf.data_ptr()
+    x = xs.detach().to(torch.float32).contiguous().view(N * B, d)
+    hid = torch.empty(6, N * B, 64, dtype=torch.float32, device=device)
+    dout = torch.empty(N * B, d, dtype=torch.float32, device=device)
+    lam0 = torch.empty(B, d, dtype=torch.float32, device=device)
+    wv = w.detach().to(torch.float32).contiguous().view(B)
+    ln = lam_n.detach().to(torch.float32).contiguous()
+    zz = z.detach().to(torch.float32).contiguous() if (ito and z is not None) else None
+    ws = _WS.get(lib.sdeng_kl_adjoint_workspace_bytes(C.byref(desc)), device)
+    desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel()
+    adj = L.Adjoint()
+    adj.xs, adj.noise, adj.w, adj.lam_in, adj.lam_out = x.data_ptr(), (zz.data_ptr() if zz is not None else None), wv.data_ptr(), ln.data_ptr(), lam0.data_ptr()
+    adj.a0, adj.a1, adj.a2, adj.d0, adj.d1, adj.d2 = (hid[i].data_ptr() for i in range(6))
+    adj.dout = dout.data_ptr()
+    dst = torch.empty(N, B, dtype=torch.float32, device=device) if score else None
+    if score:
+        adj.dst, adj.detach_score = dst.data_ptr(), int(bool(ctrl.detach_score))
+    L.check(lib.sdeng_kl_adjoint(C.byref(desc), C.byref(adj), _stream_ptr(device)))
+    return dict(x=x, a0=hid[0], a1=hid[1], a2=hid[2], d0=hid[3], d1=hid[4], d2=hid[5], dout=dout, gx=None, dst=dst), lam0
+
+
 def ctrl_forward(ctrl, t: float, x: torch.Tensor, score_gain=1.0, lerp_w=0.0):
     """sdeng_ctrl_forward: u = ctrl(t, x) for a ClippedCtrl / ScoreCtrl / LerpCtrl module, computed in HIP."""
     require_gpu(x)

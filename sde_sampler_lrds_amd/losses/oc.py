@@ -149,6 +149,7 @@ class BaseOCLoss:
         self._coef_cache = {}
         self._cpu_sde = None
         self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
+        self.native_adjoint = True  # KL training of a ClippedCtrl with no / a diagonal reference: the adjoint recursion as ONE launch (sdeng_kl_adjoint); False: one sdeng_ctrl_vjp per step
         self.fused_training = True  # ClippedCtrl over a FourierMLP: the batched control pass of training as ONE fused HIP forward + backward (sdeng_ctrl_vjp); False: the eager torch pass
         self.graph_training = False  # True: the batched control pass of log-variance training (forward + backward) is replayed as a hipGraph (_IntegralPass)
         self._graphed = {}
@@ -330,7 +331,24 @@ class BaseOCLoss:
         with torch.enable_grad():
             xN = x_n.detach().requires_grad_(True)
             lam, = torch.autograd.grad((w * terminal(xN).view(B, 1)).sum(), xN)
-            if fused:
+            ref_kind = E.resolve_reference(reference_ctrl) if reference_ctrl is not None else ("none", {})
+            native = self.native_adjoint and E.adjoint_ctrl_ok(ctrl) and E.diagonal_reference(*ref_kind)
+            if native:
+                # ClippedCtrl (every RDS / LRDS solver at its defaults) or ScoreCtrl on a diagonal mixture target (DDS / PIS on the mixture
+                # benchmarks, BASELINE config 1), no / a diagonal reference: the whole recursion below is ONE launch (sdeng_kl_adjoint:
+                # lambda in registers, u recomputed, Hessian-vector products of the mixtures in closed form); the parameter gradients come
+                # from the per-row arrays, as in log-variance training, the score model's from its N cotangents.
+                arrays, _ = E.kl_adjoint(ctrl, coef, xs[:-1], z if ito else None, w, lam, lin=lin, ito=ito, ref=ref_kind)
+                found = vjp_param_grads(ctrl, coef[:, 0].contiguous(), arrays, N, B)
+                sm = getattr(ctrl, "score_model", None)
+                sm_params = [p for p in sm.parameters() if p.requires_grad] if (arrays["dst"] is not None and sm is not None) else []
+                if sm_params:
+                    st = ctrl.clipped_score_model(coef[:, 0].contiguous().view(-1, 1), None).view(N)
+                    sm_grads = torch.autograd.grad(st, sm_params, grad_outputs=arrays["dst"].sum(1), allow_unused=True)
+                    found.update({p: g for p, g in zip(sm_params, sm_grads) if g is not None})
+                grads = [found.get(p, torch.zeros_like(p)) for p in params]
+                fused = True
+            elif fused:
                 # ClippedCtrl over the FourierMLP (every RDS / LRDS solver): the control's part of each step's vector-Jacobian product is
                 # the fused HIP forward + backward of that time step (sdeng_ctrl_vjp; weights packed once per call), the reference score's
                 # part a small torch VJP; the parameter gradients come from the per-row arrays at the end, as in log-variance training.
@@ -353,7 +371,7 @@ class BaseOCLoss:
                         lam = (1.0 + c[4] * c[1]) * lam + gx if jl is None else (1.0 + c[4] * c[1]) * lam + (c[4] * c[3]) * jl + gx
                 found = vjp_param_grads(ctrl, coef[:, 0].contiguous(), sess.arrays(), N, B)
                 grads = [found.get(p, torch.zeros_like(p)) for p in params]
-            for k in (range(N - 1, -1, -1) if not fused else ()):
+            for k in (range(N - 1, -1, -1) if not (fused or native) else ()):
                 c = coef[k]
                 xk = xs[k].detach().requires_grad_(True)
                 u = ctrl(c[0], xk)

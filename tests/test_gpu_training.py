@@ -4,6 +4,7 @@ reference by tests/golden/gen_golden.py, same counter-based noise)."""
 import pytest
 import torch
 
+from sde_sampler_lrds_amd import _lib as L
 from sde_sampler_lrds_amd import engine as E
 from tests import build_cases as bc
 from tests import golden_cases as gc
@@ -159,3 +160,130 @@ def test_fused_forward_backward_of_the_drift_net_matches_autograd(gpu, d, N, B, 
     assert egx < 2e-5
     if clip is not None and clip < 1.0:
         assert n_clipped > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,lin,ito,N,B,clip,score", [
+    (5, 0, True, True, 6, 37, 1e4, None), (16, 1, False, True, 9, 20, 1e4, None), (40, 3, True, False, 5, 64, 0.05, None),
+    (128, 4, True, True, 7, 37, 1e4, None), (100, 2, False, True, 4, 48, 1e4, None),
+    # ScoreCtrl on a diagonal mixture target (BASELINE config 1 is DDS on TwoModes d=2): (components, detach_score, clip_score)
+    (2, 0, True, True, 8, 50, 1e4, (2, False, 1e4)), (16, 0, False, True, 6, 33, 1e4, (3, False, 2.0)), (8, 2, True, True, 5, 40, 1e4, (4, True, 1e4)),
+    (128, 0, True, True, 4, 24, 1e4, (2, False, 1e4))])
+def test_native_kl_adjoint_matches_autograd(gpu, d, K, lin, ito, N, B, clip, score):
+    """sdeng_kl_adjoint (csrc/grad_kernel.hpp k_kl_adjoint): the whole adjoint recursion of KL training in one launch -- lambda_0 and every
+    parameter gradient against fp64 torch autograd of the same recursion (one step at a time, the control and the noised reference score
+    as torch expressions).  K = 0: no reference drift; K = 1: Gaussian; K > 1: diagonal mixture (closed-form Hessian-vector product).
+    The bound: 2e-5, or 6 x what the SAME recursion in fp32 torch autograd differs from fp64 by (the recursion amplifies round-off)."""
+    import copy
+
+    from sde_sampler_lrds_amd.distr.gauss import GMM, score_mog
+    from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
+    from sde_sampler_lrds_amd.losses.oc import vjp_param_grads
+    from sde_sampler_lrds_amd.models.mlp import TimeEmbed
+    from sde_sampler_lrds_amd.models.reparam import ClippedCtrl, ScoreCtrl
+    torch.manual_seed(3 * d + K)
+    tgt_par = None
+    if score is None:
+        ctrl = ClippedCtrl(base_model=cfgs._net(d), clip_model=clip).to(gpu)
+    else:
+        Kt, detach, clip_score = score
+        tgt_par = dict(loc=1.5 * torch.randn(Kt, d), scale=0.5 + torch.rand(Kt, d), mixture_weights=0.5 + torch.rand(Kt))
+        target = GMM(dim=d, **{k: v.clone() for k, v in tgt_par.items()}).to(gpu)
+        sm = TimeEmbed(dim_out=1, activation=torch.nn.GELU(), num_layers=4, channels=64)
+        torch.nn.init.normal_(sm.out_layer.weight, std=0.1)
+        torch.nn.init.constant_(sm.out_layer.bias, 0.3)
+        ctrl = ScoreCtrl(base_model=cfgs._net(d), score_model=sm, target_score=target.score, detach_score=detach, clip_score=clip_score,
+                         clip_model=clip, scale_score=0.7).to(gpu)
+    coef = torch.zeros(N, L.NCOEF, device=gpu)
+    coef[:, 0] = torch.linspace(0.9, 0.1, N)
+    coef[:, 1] = (0.9 + 0.2 * torch.rand(N)) if lin else -0.5 * torch.rand(N)
+    coef[:, 2] = 0.3 + 0.5 * torch.rand(N)
+    coef[:, 3] = 0.2 + 0.3 * torch.rand(N)
+    coef[:, 4] = 0.05 + 0.1 * torch.rand(N)
+    coef[:, 5] = 0.2 + 0.2 * torch.rand(N)
+    coef[:, 9], coef[:, 10], coef[:, 11] = 0.5 + 0.5 * torch.rand(N), 0.1 + 0.5 * torch.rand(N), 0.3 + 0.6 * torch.rand(N)
+    xs = 1.2 * torch.randn(N, B, d, device=gpu)
+    z = torch.randn(N, B, d, device=gpu)
+    w = torch.rand(B, 1, device=gpu) / B
+    w[::5] = 0.0  # filtered particles
+    lam_n = 0.1 * torch.randn(B, d, device=gpu)
+    ref = ("none", {})
+    if K == 1:
+        ref = ("gaussian", dict(x_init=torch.randn(d, device=gpu), var_init=0.5 + torch.rand(d, device=gpu)))
+    elif K > 1:
+        ref = ("gmm", dict(means_init=1.5 * torch.randn(K, d, device=gpu), variances_init=0.4 + torch.rand(K, d, device=gpu), weights_init=0.5 + torch.rand(K, device=gpu)))
+    arrays, lam0 = E.kl_adjoint(ctrl, coef, xs, z, w, lam_n, lin=lin, ito=ito, ref=ref)
+    found = vjp_param_grads(ctrl, coef[:, 0].contiguous(), arrays, N, B)
+    if score is not None:
+        sm_params = list(ctrl.score_model.parameters())
+        st = ctrl.clipped_score_model(coef[:, 0].contiguous().view(-1, 1), None).view(N)
+        found.update(dict(zip(sm_params, torch.autograd.grad(st, sm_params, grad_outputs=arrays["dst"].sum(1)))))
+
+    def recursion(dtype):  # torch autograd of the same recursion, one step at a time
+        if score is None:
+            cc = copy.deepcopy(ctrl).to(dtype)
+        else:
+            t2 = GMM(dim=d, **{k: v.clone().to(dtype) for k, v in tgt_par.items()}).to(gpu).to(dtype)
+            cc = ScoreCtrl(base_model=copy.deepcopy(ctrl.base_model).to(dtype), score_model=copy.deepcopy(ctrl.score_model).to(dtype), target_score=t2.score,
+                           detach_score=ctrl.detach_score, clip_score=ctrl.clip_score, clip_model=ctrl.clip_model, scale_score=ctrl.scale_score)
+        params = list(cc.parameters())
+        grads = [torch.zeros_like(p) for p in params]
+        lam, c_, wd = lam_n.to(dtype), coef.to(dtype), w.to(dtype)
+        for k in range(N - 1, -1, -1):
+            c = c_[k]
+            xk = xs[k].to(dtype).requires_grad_(True)
+            u = cc(c[0], xk)
+            rf = None
+            if K == 1:
+                rf = -(xk - c[9] * ref[1]["x_init"].to(dtype)) / (c[10] + c[11] * ref[1]["var_init"].to(dtype))
+            elif K > 1:
+                rf = score_mog(xk, ref[1]["weights_init"].to(dtype), c[9] * ref[1]["means_init"].to(dtype), c[10] + c[11] * ref[1]["variances_init"].to(dtype))
+            zk = z[k].to(dtype)
+            uu, uz = (u * u).sum(-1, keepdim=True), (u * zk).sum(-1, keepdim=True)
+            if lin:
+                x_next = c[1] * xk + c[2] * (u if rf is None else rf + u) + c[3] * zk
+                dr = c[4] * uu + (c[5] * uz if ito else 0.0)
+            else:
+                drift = c[1] * xk if rf is None else c[1] * xk + c[3] * rf
+                x_next = xk + (drift + c[2] * u) * c[4] + c[2] * (c[5] * zk)
+                dr = 0.5 * uu * c[4] + (c[5] * uz if ito else 0.0)
+            got = torch.autograd.grad((lam * x_next).sum() + (wd * dr).sum(), [xk] + params, allow_unused=True)
+            lam = got[0]
+            for acc, gk in zip(grads, got[1:]):
+                if gk is not None:
+                    acc += gk
+        return lam, dict(zip([n for n, _ in cc.named_parameters()], grads))
+
+    lam64, g64 = recursion(torch.float64)
+    lam32, g32 = recursion(torch.float32)
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp(min=1e-30))  # noqa: E731
+    e_lam, t_lam = rel(lam0, lam64), rel(lam32, lam64)
+    worst, t_worst = 0.0, 0.0
+    for name, p in ctrl.named_parameters():
+        if p not in found:
+            assert float(g64[name].abs().max()) == 0.0, name
+            continue
+        worst, t_worst = max(worst, rel(found[p], g64[name])), max(t_worst, rel(g32[name], g64[name]))
+    print(f"kl_adjoint d={d} K={K} {'LIN' if lin else 'EM'} ito={ito} N={N} B={B} clip={clip} score={score}: lambda_0 error {e_lam:.2e} (fp32 torch autograd: "
+          f"{t_lam:.2e}), worst parameter-gradient error {worst:.2e} (fp32 torch: {t_worst:.2e}), vs fp64 autograd")
+    assert e_lam < max(2e-5, 6 * t_lam) and worst < max(2e-5, 6 * t_worst)
+
+
+@pytest.mark.gpu
+def test_kl_training_native_adjoint_equals_the_stepwise_one(gpu):
+    """The one-launch adjoint and the step-by-step one (sdeng_ctrl_vjp per step + torch VJP of the reference score) give the same gradients."""
+    c = gc.load("train_kl_ei_gmm_d16")
+    c.meta["kind"] = KINDS["train_lv"]
+    out = {}
+    for native in (True, False):
+        b = bc.build(c, gpu)
+        loss = b["loss"]
+        loss.method, loss.native_adjoint = "kl", native
+        loss.seed = c.meta["seed"]
+        value, _ = loss(b["ts"], b["x0"], *b["args"])
+        value.backward()
+        out[native] = (float(value.detach()), {k: p.grad.clone() for k, p in loss.generative_ctrl.named_parameters() if p.grad is not None})
+    assert out[True][0] == out[False][0]
+    worst = max(float((out[True][1][k] - g).abs().max() / g.abs().max().clamp(min=1e-30)) for k, g in out[False][1].items())
+    print(f"native vs stepwise adjoint: worst relative gradient difference {worst:.2e}")
+    assert worst < 1e-5
