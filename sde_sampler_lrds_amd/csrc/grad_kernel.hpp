@@ -263,9 +263,9 @@ struct AdjArgs {
   int lin;                // 1: FORM_LIN, 0: FORM_EM
   int ntiles_b;           // ceil(B / 16)
   // ScoreCtrl (models/reparam.py:63-117): u = clip(net) + scale clip(score_pi(x)) s_theta(t) on a diagonal mixture target
-  int has_score;          // 0: ClippedCtrl
+  int has_score;          // ADJ_NONE: ClippedCtrl; ADJ_GMM / ADJ_PHI4: ScoreCtrl on that target
   const float* stheta;    // [N] clipped s_theta(t_k), or nullptr (no score model: 1)
-  DistDev target;         // SDENG_DIST_GMM_DIAG tables (k_dist_tables)
+  DistDev target;         // SDENG_DIST_GMM_DIAG tables (k_dist_tables), or the PHI4 constants
   float scale_score, clip_score;
   int score_detached;     // detach_score: the target score is a constant of x (no Hessian term in the state gradient)
   float* dst;             // [N * B] <cot, scale clip(score)>: the cotangent of s_theta(t_k), per particle
@@ -331,7 +331,30 @@ SD_INLINE void gmm_hvp(const f32x4 (&x)[NT], const float* __restrict__ tab, cons
     for (int r = 0; r < 4; ++r) out[t][r] = __builtin_fmaf(-Q[t][r], qs, T[t][r] * inv);
 }
 
-template <int NT, bool SCORE>
+// H(x) v for the phi^4 lattice score s_i = A (x_i^3 - x_i) + K0 + C (2 x_i - x_{i+1} - x_{i-1}) (phi4_score, distr/phi_four.py:81-96):
+// (A (3 x_i^2 - 1) + 2 C) v_i - C (v_{i+1} + v_{i-1}), Dirichlet-0 neighbours (v is 0 on pad features)
+template <int NT>
+SD_INLINE void phi4_hvp(const f32x4 (&x)[NT], const DistDev& ds, int d, int g, int lane, const f32x4 (&v)[NT], f32x4 (&out)[NT]) {
+  const float coef = ds.p0 * static_cast<float>(d);
+  const float A = -ds.p2 / coef, C = -ds.p2 * coef;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float le, re;
+    phi4_edges<NT>(v, t, g, lane, le, re);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xv = x[t][r], vv = v[t][r];
+      const float vl = (r == 0) ? le : v[t][r > 0 ? r - 1 : 0];
+      const float vr = (r == 3) ? re : v[t][r < 3 ? r + 1 : 3];
+      const float diag = __builtin_fmaf(A, __builtin_fmaf(3.0f * xv, xv, -1.0f), 2.0f * C);
+      const float hv = __builtin_fmaf(diag, vv, -C * (vl + vr));
+      out[t][r] = feat_live<NT>(t, r, 4 * g, d) ? hv : 0.0f;
+    }
+  }
+}
+
+enum { ADJ_NONE = 0, ADJ_GMM = 1, ADJ_PHI4 = 2 };  // target of the ScoreCtrl the adjoint differentiates (0: ClippedCtrl)
+template <int NT, int SCORE>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const AdjArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VjpArgs& v = a.v;
@@ -364,11 +387,12 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
         gmm_hvp<NT>(x, a.ref_tab + static_cast<size_t>(k) * a.ref_k * 2 * dpad, a.ref_consts + static_cast<size_t>(k) * a.ref_k * 2, 2, a.ref_k, a.ref_c1, g,
                     lam, jl);
       }
-      f32x4 sr[SCORE ? NT : 1], gfull[SCORE ? NT : 1];  // ScoreCtrl: raw target score, and the cotangent of the whole control (before the net's clip mask)
+      f32x4 sr[SCORE != ADJ_NONE ? NT : 1], gfull[SCORE != ADJ_NONE ? NT : 1];  // ScoreCtrl: raw target score, and the cotangent of the whole control (before the net's clip mask)
       float gain_st = 0.0f;
-      if constexpr (SCORE) {
+      if constexpr (SCORE != ADJ_NONE) {
         asm volatile("" ::: "memory");
-        gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, sr);
+        if constexpr (SCORE == ADJ_GMM) gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, sr);
+        else phi4_score<NT>(x, a.target, v.d, g, lane, sr);
         gain_st = a.scale_score * (a.stheta ? a.stheta[k] : 1.0f);
       }
       vjp_tile<NT, true>(v, lds, lds_t, bias, ns, trash, row, live, v.temb + static_cast<size_t>(k) * SD_H, lane, x, true, true,
@@ -378,14 +402,14 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
 #pragma unroll
                            for (int r = 0; r < 4; ++r) {
                              float uv = u[r];
-                             if constexpr (SCORE) uv = __builtin_fmaf(gain_st, a.clip_score > 0.0f ? clampf(sr[t][r], a.clip_score) : sr[t][r], uv);
+                             if constexpr (SCORE != ADJ_NONE) uv = __builtin_fmaf(gain_st, a.clip_score > 0.0f ? clampf(sr[t][r], a.clip_score) : sr[t][r], uv);
                              c[r] = __builtin_fmaf(alpha, lam[t][r], __builtin_fmaf(beta, uv, gamma * z[r]));
                            }
-                           if constexpr (SCORE) gfull[t] = c;
+                           if constexpr (SCORE != ADJ_NONE) gfull[t] = c;
                            return c;
                          },
                          gx);
-      if constexpr (SCORE) {
+      if constexpr (SCORE != ADJ_NONE) {
         // d u / d s_theta = scale clip(score): its cotangent, one number per (step, particle); d u / d x through the score: scale s_theta H_pi,
         // under the clip's mask (torch.clip passes the gradient where |score| <= clip_score)
         float ds = 0.0f;
@@ -402,7 +426,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
         if (live && g == 0) a.dst[row] = ds;
         if (!a.score_detached) {
           asm volatile("" ::: "memory");
-          gmm_hvp<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, gm, hv);
+          if constexpr (SCORE == ADJ_GMM) gmm_hvp<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, gm, hv);
+          else phi4_hvp<NT>(x, a.target, v.d, g, lane, gm, hv);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -437,7 +462,7 @@ static int launch_ctrl_vjp(const VjpArgs& a, int grid, hipStream_t stream) {
   }
   return static_cast<int>(hipGetLastError());
 }
-template <int NT, bool SCORE>
+template <int NT, int SCORE>
 static int launch_kl_adjoint_s(const AdjArgs& a, int grid, hipStream_t stream) {
   const size_t lds_bytes = static_cast<size_t>(2 * sd_off_wout(NT)) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kl_adjoint<NT, SCORE>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
@@ -447,7 +472,9 @@ static int launch_kl_adjoint_s(const AdjArgs& a, int grid, hipStream_t stream) {
 }
 template <int NT>
 static int launch_kl_adjoint(const AdjArgs& a, int grid, hipStream_t stream) {
-  return a.has_score ? launch_kl_adjoint_s<NT, true>(a, grid, stream) : launch_kl_adjoint_s<NT, false>(a, grid, stream);
+  if (a.has_score == ADJ_GMM) return launch_kl_adjoint_s<NT, ADJ_GMM>(a, grid, stream);
+  if (a.has_score == ADJ_PHI4) return launch_kl_adjoint_s<NT, ADJ_PHI4>(a, grid, stream);
+  return launch_kl_adjoint_s<NT, ADJ_NONE>(a, grid, stream);
 }
 #define SD_DEFINE_VJP(NT) \
   int sd_launch_vjp_##NT(const VjpArgs& a, int grid, hipStream_t s) { return launch_ctrl_vjp<NT>(a, grid, s); } \

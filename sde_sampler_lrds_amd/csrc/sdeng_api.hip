@@ -832,9 +832,10 @@ static int check_adjoint(const sdeng_desc* d) {
   if (d->abi_version != SDENG_ABI_VERSION) return fail(SDENG_E_INVALID, "ABI version %d, library has %d", d->abi_version, SDENG_ABI_VERSION);
   if (d->d < 1 || d->d > 128 || d->N < 1 || d->B < 1 || !d->coef) return fail(SDENG_E_INVALID, "bad sizes (1 <= d <= 128, N, B >= 1) or null coef");
   if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM) return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: forward forms LIN / EM (form %d)", d->form);
-  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && !(d->net.ctrl_kind == SDENG_CTRL_SCORE && d->target.kind == SDENG_DIST_GMM_DIAG))
-    return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: ClippedCtrl, or ScoreCtrl on a diagonal mixture target (ctrl_kind %d, target kind %d)", d->net.ctrl_kind,
-                d->target.kind);
+  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED &&
+      !(d->net.ctrl_kind == SDENG_CTRL_SCORE && (d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_PHI4)))
+    return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: ClippedCtrl, or ScoreCtrl on a diagonal mixture / phi^4 target (ctrl_kind %d, target kind %d)",
+                d->net.ctrl_kind, d->target.kind);
   if (d->ref.kind != SDENG_REF_NONE && d->ref.kind != SDENG_REF_GAUSS_DIAG && d->ref.kind != SDENG_REF_GMM_DIAG)
     return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: no reference, or a diagonal Gaussian / mixture reference (ref.kind %d)", d->ref.kind);
   if (d->ref.kind != SDENG_REF_NONE && ((d->ref.kind == SDENG_REF_GMM_DIAG && d->ref.k < 1) || !d->ref.means_init || !d->ref.vars_init))
@@ -890,7 +891,7 @@ extern "C" int sdeng_kl_adjoint(const sdeng_desc* d, const sdeng_adjoint* adj, v
     a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
   }
   if (score) {
-    a.has_score = 1;
+    a.has_score = d->target.kind == SDENG_DIST_PHI4 ? 2 : 1;  // grad_kernel.hpp ADJ_PHI4 / ADJ_GMM
     if (d->net.score_model.n_hidden > 0) {
       TimeEmbedArgs sm;
       sm.te = d->net.score_model; sm.coef = d->coef; sm.col = 0; sm.t_direct = 0; sm.t_value = 0.0f;

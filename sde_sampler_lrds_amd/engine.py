@@ -826,7 +826,7 @@ def diagonal_reference(kind, utils) -> bool:
 
 def adjoint_ctrl_ok(ctrl) -> bool:
     """Does sdeng_kl_adjoint differentiate this control?  ClippedCtrl over a FourierMLP, or a plain ScoreCtrl over one whose target is a
-    diagonal mixture (BASELINE config 1: DDS on TwoModes) and whose score model, if any, is a TimeEmbed."""
+    diagonal mixture or the phi^4 lattice (BASELINE configs 1 and 3: DDS on TwoModes, PIS on PhiFour) and whose score model, if any, is a TimeEmbed."""
     name = type(ctrl).__name__
     if type(getattr(ctrl, "base_model", None)).__name__ != "FourierMLP":
         return False
@@ -835,7 +835,14 @@ def adjoint_ctrl_ok(ctrl) -> bool:
     if name != "ScoreCtrl":
         return False
     tgt = _self_of(ctrl.target_score)
-    if tgt is None or _name(tgt) not in ("GMM", "TwoModes", "ManyModes", "BracketTwoModes") or getattr(tgt, "mixture_weights", None) is None:
+    if tgt is None:
+        return False
+    if _name(tgt) == "PhiFour":
+        try:
+            dist_desc(tgt, "cpu", [])  # (the 1-D Dirichlet-0 untilted lattice only)
+        except UnsupportedByEngine:
+            return False
+    elif _name(tgt) not in ("GMM", "TwoModes", "ManyModes", "BracketTwoModes") or getattr(tgt, "mixture_weights", None) is None:
         return False
     return ctrl.score_model is None or _name(ctrl.score_model) == "TimeEmbed"
 

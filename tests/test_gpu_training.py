@@ -168,7 +168,9 @@ def test_fused_forward_backward_of_the_drift_net_matches_autograd(gpu, d, N, B, 
     (128, 4, True, True, 7, 37, 1e4, None), (100, 2, False, True, 4, 48, 1e4, None),
     # ScoreCtrl on a diagonal mixture target (BASELINE config 1 is DDS on TwoModes d=2): (components, detach_score, clip_score)
     (2, 0, True, True, 8, 50, 1e4, (2, False, 1e4)), (16, 0, False, True, 6, 33, 1e4, (3, False, 2.0)), (8, 2, True, True, 5, 40, 1e4, (4, True, 1e4)),
-    (128, 0, True, True, 4, 24, 1e4, (2, False, 1e4))])
+    (128, 0, True, True, 4, 24, 1e4, (2, False, 1e4)),
+    # ScoreCtrl on the phi^4 lattice (BASELINE config 3 is PIS on PhiFour d=100): tridiagonal Hessian, neighbours across lanes and tiles
+    (100, 0, False, True, 5, 24, 1e4, ("phi4", False, 1e4)), (36, 0, False, False, 6, 40, 1e4, ("phi4", False, 30.0)), (17, 0, True, True, 4, 20, 1e4, ("phi4", True, 1e4))])
 def test_native_kl_adjoint_matches_autograd(gpu, d, K, lin, ito, N, B, clip, score):
     """sdeng_kl_adjoint (csrc/grad_kernel.hpp k_kl_adjoint): the whole adjoint recursion of KL training in one launch -- lambda_0 and every
     parameter gradient against fp64 torch autograd of the same recursion (one step at a time, the control and the noised reference score
@@ -177,6 +179,7 @@ def test_native_kl_adjoint_matches_autograd(gpu, d, K, lin, ito, N, B, clip, sco
     import copy
 
     from sde_sampler_lrds_amd.distr.gauss import GMM, score_mog
+    from sde_sampler_lrds_amd.distr.phi_four import PhiFour
     from sde_sampler_lrds_amd.experiments import baseline_configs as cfgs
     from sde_sampler_lrds_amd.losses.oc import vjp_param_grads
     from sde_sampler_lrds_amd.models.mlp import TimeEmbed
@@ -187,8 +190,11 @@ def test_native_kl_adjoint_matches_autograd(gpu, d, K, lin, ito, N, B, clip, sco
         ctrl = ClippedCtrl(base_model=cfgs._net(d), clip_model=clip).to(gpu)
     else:
         Kt, detach, clip_score = score
-        tgt_par = dict(loc=1.5 * torch.randn(Kt, d), scale=0.5 + torch.rand(Kt, d), mixture_weights=0.5 + torch.rand(Kt))
-        target = GMM(dim=d, **{k: v.clone() for k, v in tgt_par.items()}).to(gpu)
+        if Kt == "phi4":
+            target = PhiFour(a=0.1, b=0.05, dim=d, beta=20.0).to(gpu)
+        else:
+            tgt_par = dict(loc=1.5 * torch.randn(Kt, d), scale=0.5 + torch.rand(Kt, d), mixture_weights=0.5 + torch.rand(Kt))
+            target = GMM(dim=d, **{k: v.clone() for k, v in tgt_par.items()}).to(gpu)
         sm = TimeEmbed(dim_out=1, activation=torch.nn.GELU(), num_layers=4, channels=64)
         torch.nn.init.normal_(sm.out_layer.weight, std=0.1)
         torch.nn.init.constant_(sm.out_layer.bias, 0.3)
@@ -223,7 +229,10 @@ def test_native_kl_adjoint_matches_autograd(gpu, d, K, lin, ito, N, B, clip, sco
         if score is None:
             cc = copy.deepcopy(ctrl).to(dtype)
         else:
-            t2 = GMM(dim=d, **{k: v.clone().to(dtype) for k, v in tgt_par.items()}).to(gpu).to(dtype)
+            if score[0] == "phi4":
+                t2 = PhiFour(a=0.1, b=0.05, dim=d, beta=20.0).to(gpu).to(dtype)
+            else:
+                t2 = GMM(dim=d, **{k: v.clone().to(dtype) for k, v in tgt_par.items()}).to(gpu).to(dtype)
             cc = ScoreCtrl(base_model=copy.deepcopy(ctrl.base_model).to(dtype), score_model=copy.deepcopy(ctrl.score_model).to(dtype), target_score=t2.score,
                            detach_score=ctrl.detach_score, clip_score=ctrl.clip_score, clip_model=ctrl.clip_model, scale_score=ctrl.scale_score)
         params = list(cc.parameters())
