@@ -80,7 +80,7 @@ def test_full_covariance_target_limits_are_loud(gpu):
         model.evaluate()
     pis = make_model("pis_orig", "default", "lv", "em", "target_informed_zero_init", "uniform", dict(sigma=0.4472135954999579), tgt, _train(256), n_steps=8)
     from sde_sampler_lrds_amd import _lib as L
-    with pytest.raises((E.UnsupportedByEngine, L.EngineError), match="target kind 8"):  # sdeng_ctrl_forward has no staged-precision path
+    with pytest.raises((E.UnsupportedByEngine, L.EngineError), match="TwoModesFull|target kind 8"):  # no stand-alone HIP evaluation of this control (sdeng_ctrl_forward has no staged-precision path)
         E.ctrl_forward(pis.generative_ctrl, 0.5, torch.zeros(4, 8, device=gpu))
     u = pis.generative_ctrl(torch.tensor(0.5, device=gpu), torch.zeros(4, 8, device=gpu))  # (the module's own torch forward, as upstream)
     assert u.shape == (4, 8) and torch.isfinite(u).all()
