@@ -76,9 +76,56 @@ class _FusedIntegral(torch.autograd.Function):
         t_unique, xs, zc = ctx.saved_tensors
         N, B, d = ctx.shape
         cot = zc.view(N, B, d) * grad_s.view(1, B, 1)  # d loss / d u_kb
-        grads = vjp_param_grads(ctx.ctrl, t_unique, E.ctrl_vjp(ctx.ctrl, t_unique, xs, cot), N, B)
-        params = [p for p in ctx.ctrl.parameters() if p.requires_grad]
+        ctrl = ctx.ctrl
+        net_view = fused_net_view(ctrl)
+        grads = vjp_param_grads(net_view, t_unique, E.ctrl_vjp(net_view, t_unique, xs, cot), N, B)
+        sm = getattr(ctrl, "score_model", None)
+        sm_params = [p for p in sm.parameters() if p.requires_grad] if (net_view is not ctrl and sm is not None) else []
+        if sm_params:
+            # ScoreCtrl: u = clip(net) + scale clip(score_pi(x)) s_theta(t).  The states are constants, so the score part only reaches the
+            # score model: d loss / d s_theta(t_k) = sum_b <cot_kb, scale clip(score_pi(x_kb))> (HIP score kernel, one launch for all rows)
+            from ..models.reparam import _clip
+            _, sc = E.dist_eval(E.ctrl_target(ctrl)[0], xs.reshape(N * B, d), want_logp=False, want_score=True)
+            dst = (cot.reshape(N * B, d) * (ctrl.scale_score * _clip(sc, ctrl.clip_score))).sum(-1).view(N, B).sum(1)
+            with torch.enable_grad():
+                st = ctrl.clipped_score_model(t_unique.view(-1, 1), None).view(N)
+                sm_grads = torch.autograd.grad(st, sm_params, grad_outputs=dst, allow_unused=True)
+            grads.update({p: g for p, g in zip(sm_params, sm_grads) if g is not None})
+        params = [p for p in ctrl.parameters() if p.requires_grad]
         return (None, None, None, None) + tuple(grads.get(p) for p in params)
+
+
+_NET_VIEWS = {}
+
+
+def fused_training_ok(ctrl) -> bool:
+    """Controls whose batched log-variance pass is the fused HIP forward + backward: ClippedCtrl over a FourierMLP, and a plain ScoreCtrl
+    over one (its score part has no state gradient to take in this pass) on a target the score kernel knows."""
+    if type(getattr(ctrl, "base_model", None)).__name__ != "FourierMLP":
+        return False
+    if type(ctrl).__name__ == "ClippedCtrl":
+        return True
+    if type(ctrl).__name__ != "ScoreCtrl" or not (ctrl.score_model is None or type(ctrl.score_model).__name__ == "TimeEmbed"):
+        return False
+    try:
+        E.dist_desc(E.ctrl_target(ctrl)[0], "cpu", [])
+    except E.UnsupportedByEngine:
+        return False
+    return True
+
+
+def fused_net_view(ctrl):
+    """The ClippedCtrl part of a ScoreCtrl (same drift net, same clip) as sdeng_ctrl_vjp wants it; a ClippedCtrl is its own view."""
+    if type(ctrl).__name__ == "ClippedCtrl":
+        return ctrl
+    view = _NET_VIEWS.get(id(ctrl))
+    if view is None or view[0]() is not ctrl or view[1].clip_model != ctrl.clip_model:
+        import weakref
+
+        from ..models.reparam import ClippedCtrl
+        view = (weakref.ref(ctrl), ClippedCtrl(base_model=ctrl.base_model, clip_model=ctrl.clip_model))
+        _NET_VIEWS[id(ctrl)] = view
+    return view[1]
 
 
 def vjp_param_grads(ctrl, t_unique, r, N, B):
@@ -270,8 +317,9 @@ class BaseOCLoss:
         # RemoveReferenceCtrl: u = inner - ref_score and ref_score has no parameters, so s - s.detach() of the inner control carries the
         # same (zero) value and the same gradient
         ctrl = E.unwrap_ctrl(self.generative_ctrl)[0] if type(self.generative_ctrl).__name__ == "RemoveReferenceCtrl" else self.generative_ctrl
-        if self.fused_training and type(ctrl).__name__ == "ClippedCtrl" and type(getattr(ctrl, "base_model", None)).__name__ == "FourierMLP":
-            # the drift net of every RDS / LRDS solver (conf/model/basic.yaml): fused HIP forward + backward (csrc/grad_kernel.hpp)
+        if self.fused_training and fused_training_ok(ctrl):
+            # the drift net of every RDS / LRDS solver (conf/model/basic.yaml), and the ScoreCtrl of PIS / DDS / DIS (conf/model/score.yaml):
+            # fused HIP forward + backward of the net (csrc/grad_kernel.hpp); the score model's N cotangents from the HIP score kernel
             params = [p for p in ctrl.parameters() if p.requires_grad]
             return _FusedIntegral.apply(ctrl, t_unique, xs.contiguous(), zc.view(xs.shape), *params)
         key = (id(ctrl), tuple(xs.shape), str(xs.device))
