@@ -296,3 +296,29 @@ def test_kl_training_native_adjoint_equals_the_stepwise_one(gpu):
     worst = max(float((out[True][1][k] - g).abs().max() / g.abs().max().clamp(min=1e-30)) for k, g in out[False][1].items())
     print(f"native vs stepwise adjoint: worst relative gradient difference {worst:.2e}")
     assert worst < 1e-5
+
+
+@pytest.mark.gpu
+def test_kl_training_at_baseline_config_1_size(gpu):
+    """BASELINE config 1 as the reference runs it (DDS on TwoModes d=2, KL loss, 4 096 particles x 64 steps, cosine time grid): the one-launch
+    adjoint against the step-by-step one (torch vector-Jacobian products of the whole ScoreCtrl) on the SAME trajectory -- every gradient --
+    and two consecutive training calls must differ (fresh x0 / noise per call)."""
+    from sde_sampler_lrds_amd.experiments.benchmark_utils import make_model, make_target_details
+    tgt = make_target_details("two_modes", dim=2)
+    grads = {}
+    for native in (True, False):
+        torch.manual_seed(0)
+        model = make_model("dds_orig", "default", "kl", "em", "target_informed_zero_init", "uniform", dict(sigma=1.0), tgt,
+                           dict(train_steps=2, train_batch_size=4096, eval_batch_size=4096), optim_details=dict(lr=1e-3), n_steps=64)
+        with torch.no_grad():  # a drift net that does something (make_model zero-initialises the last layer)
+            g = torch.Generator(device="cpu").manual_seed(1)
+            model.generative_ctrl.base_model.out_layer.weight.copy_(0.05 * torch.randn(model.generative_ctrl.base_model.out_layer.weight.shape, generator=g))
+        model.loss.native_adjoint = native
+        model.setup_optim()
+        loss, _ = model.compute_loss()
+        loss.backward()
+        grads[native] = (float(loss.detach()), {k: p.grad.clone() for k, p in model.generative_ctrl.named_parameters() if p.grad is not None})
+    assert grads[True][0] == grads[False][0]
+    worst = max(float((grads[True][1][k] - g).abs().max() / g.abs().max().clamp(min=1e-30)) for k, g in grads[False][1].items())
+    print(f"cfg 1 size: native vs stepwise adjoint, worst relative gradient difference {worst:.2e} over {len(grads[False][1])} parameters")
+    assert len(grads[False][1]) >= 20 and worst < 2e-4  # (the reference's own conditioning on this target: 1e-4, fixture train_kl_dds_d2)
