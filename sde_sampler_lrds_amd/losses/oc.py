@@ -766,11 +766,11 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
         autograd pass of the control over the (N+1)*B (time, state) pairs rebuilds (:736-742)
             cost_k = (b_k + b'_k)/g + u_k - u_{k+1},   rnd = rnd0 + sum_k 0.5|cost_k|^2 dt + <cost_k, u_k.detach() - u_k> dt + <cost_k, db_k> - log pi~(x_N)
         with b_k = drift(t_k, x_k), b'_k = drift(t_{k+1}, x_{k+1})."""
-        if self.method in ("kl", "kl_ito"):
-            raise E.UnsupportedByEngine("KL training back-propagates through the whole trajectory: not on the HIP path")
         if self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None:
             raise E.UnsupportedByEngine("sde_ctrl_noise / sde_ctrl_dropout perturb the simulated control: not built")
         E.require_gpu(x)
+        if self.method in ("kl", "kl_ito"):
+            return self._kl_loss_cmcd(ts, x, terminal_unnorm_log_prob, initial_log_prob)
         seed_c = self._next_train_seed()
         x = self._x0(x, seed_c)
         if self.traj_per_sample != 1:
@@ -804,6 +804,57 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
         rnd = (0.5 * (cost ** 2).sum(-1) * dt.view(N, 1) + (cost * (u[:-1].detach() - u[:-1])).sum(-1) * dt.view(N, 1)
                + (cost * db).sum(-1)).sum(0).view(B, 1) + const
         return self.compute_loss(rnd, samples=x_n)
+
+
+    def _kl_loss_cmcd(self, ts, x, terminal_unnorm_log_prob, initial_log_prob):
+        """[TRAINING] KL methods of CMCD (losses/oc.py:830-857 on simulate(train=True): rnd0 = 0, :695-699; the un-detached control drives
+        the SDE, :706-709).  VALUE: the HIP step loop (its log-weight minus the initial log-density it adds).  GRADIENT: the discrete
+        adjoint of the reference's own step (:711-742) -- y = x + (b_s(x) + g u_s(x)) dt + g db, cost = (b_s(x) + b_t(y))/g + u_s(x) - u_t(y),
+        rnd += 0.5 |cost|^2 dt + <cost, db> -- one torch vector-Jacobian product per step over the HIP states (two control evaluations
+        share the state y, so the step is differentiated as a whole; the target / prior scores are differentiated exactly where the
+        reference's are: closed-form scores carry a graph, autograd-made ones do not, distr/base.py:146-154)."""
+        seed_c = self._next_train_seed()
+        x = self._x0(x, seed_c)
+        if self.traj_per_sample != 1:
+            x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
+        N, (B, d) = ts.numel() - 1, x.shape
+        seed_eval, self.seed = self.seed, seed_c
+        try:
+            with torch.no_grad():
+                x_n, rnd_sim, xs = self.simulate(ts, x, terminal_unnorm_log_prob, initial_log_prob=initial_log_prob, train=False, return_traj=True)
+        finally:
+            self.seed = seed_eval
+        z = E.philox_noise(seed_c, N, B, d, self.particle0, x.device)  # bit for bit the normals the kernel drew
+        rnd_val = rnd_sim.reshape(B, 1) - self._logp(initial_log_prob, x)  # (the evaluation pass starts from log p_prior(x0), training from 0)
+        mask = self.filter(rnd_val, samples=x_n)
+        assert mask.shape == rnd_val.shape
+        self.n_filtered += (mask.numel() - mask.sum()).item()
+        w = mask.to(rnd_val.dtype) / mask.sum()
+        value = rnd_val[mask].mean()
+        ctrl = self.generative_ctrl
+        params = [p for p in ctrl.parameters() if p.requires_grad]
+        grads = [torch.zeros_like(p) for p in params]
+        g = self.sde.diff_coeff
+        tdev = ts.to(x.device)
+        with torch.enable_grad():
+            xN = x_n.detach().requires_grad_(True)
+            lam, = torch.autograd.grad((w * (-terminal_unnorm_log_prob(xN).view(B, 1))).sum(), xN)
+            for k in range(N - 1, -1, -1):
+                s, t = tdev[k], tdev[k + 1]
+                dt = t - s
+                db = dt.sqrt() * z[k]
+                xk = xs[k].detach().requires_grad_(True)
+                u_s, b_s = ctrl(s, xk), self.sde.drift(s, xk)
+                y = xk + (b_s + u_s * g) * dt + g * db
+                cost = (b_s + self.sde.drift(t, y)) / g + u_s - ctrl(t, y)
+                dr = 0.5 * (cost ** 2).sum(-1, keepdim=True) * dt + (cost * db).sum(-1, keepdim=True)
+                got = torch.autograd.grad((lam * y).sum() + (w * dr).sum(), [xk] + params, allow_unused=True)
+                lam = got[0]
+                for acc, gk in zip(grads, got[1:]):
+                    if gk is not None:
+                        acc += gk
+        surrogate = sum(((p - p.detach()) * gr).sum() for p, gr in zip(params, grads))
+        return value.detach() + surrogate, {"train/n_filtered_cumulative": self.n_filtered}
 
 
 class DiscreteTimeReversalLossEI(_InitialLogProbLoss):

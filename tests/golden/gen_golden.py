@@ -360,19 +360,20 @@ def case_train_lv_dis_orig(name, d, K, B, N, seed, method="lv"):
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
 
 
-def case_train_lv_cmcd(name, d, K, B, N, seed):
-    """ControlledLangevinSDELoss.__call__ (losses/oc.py:830-857), method='lv', mixture target, IsotropicGauss prior."""
+def case_train_lv_cmcd(name, d, K, B, N, seed, method="lv"):
+    """ControlledLangevinSDELoss.__call__ (losses/oc.py:830-857), method='lv' (or 'kl': back-propagation through simulate(train=True),
+    rnd0 = 0, :695-699), mixture target, IsotropicGauss prior."""
     torch.manual_seed(seed)
     target = r_gauss.ManyModes(n_modes=K, dim=d, var=0.5, seed_loc=42, n_reference_samples=10)
     prior = r_gauss.IsotropicGauss(dim=d, scale=2.0)
     sde = r_sdes.ControlledLangevinSDE(target_score=target.score, prior_score=prior.score, diff_coeff=1.0, terminal_t=1.0, clip_score=1e5)
     ctrl = r_rep.ScoreCtrl(base_model=liven(fourier_mlp(d)), score_model=score_time_embed(bias=0.01), target_score=target.score,
                            detach_score=False, clip_score=1e4, clip_model=1e4, scale_score=1.0)
-    loss = r_oc.ControlledLangevinSDELoss(ctrl, ctrl, sde=sde, method="lv", max_rnd=1e8)
+    loss = r_oc.ControlledLangevinSDELoss(ctrl, ctrl, sde=sde, method=method, max_rnd=1e8)
     ts = torch.linspace(0.0, 1.0, N + 1)
     x0 = 2.0 * orc.philox_normal(seed, 0, 0, B, d, stream=1)
     meta = dict(kind="train_lv_cmcd", d=d, K=K, B=B, N=N, seed=seed, diff_coeff=1.0, T=1.0, clip_langevin=1e5, clip_model=1e4,
-                clip_score=1e4, scale_score=1.0, prior_kind="iso", prior_scale=2.0)
+                clip_score=1e4, scale_score=1.0, prior_kind="iso", prior_scale=2.0, method=method)
     arrays = dict(ts=ts, x0=x0, tgt_loc=target.loc, tgt_scale=target.scale, tgt_w=target.mixture_weights)
     _train_fixture(name, meta, arrays, ctrl, lambda: loss(ts, x0.clone(), target.unnorm_log_prob, initial_log_prob=prior.log_prob))
 
@@ -993,6 +994,7 @@ CASES = {
     "train_kl_dis_ei_d8": lambda n: case_train_lv_dis(n, d=8, K=4, B=64, N=32, seed=173, method="kl"),
     "train_kl_dis_orig_d8": lambda n: case_train_lv_dis_orig(n, d=8, K=4, B=64, N=64, seed=176, method="kl"),
     "train_kl_pis_phi4_d100": lambda n: case_train_lv_pis(n, d=100, B=32, N=16, seed=175, dt=5.0 / 512, method="kl"),
+    "train_kl_cmcd_gmm_d16": lambda n: case_train_lv_cmcd(n, d=16, K=4, B=64, N=32, seed=177, method="kl"),
     # config 3 (PhiFour d=100, PIS, EM), at the real step size 5/512
     "pis_em_phi4_d100": lambda n: case_pis_phi4(n, d=100, B=64, N=32, seed=21, dt=5.0 / 512),
     # config 1 (TwoModes d=2, DDS) and the Rings target on the same solver

@@ -44,7 +44,7 @@ def test_lv_training_loss_and_gradients_match_reference(gpu, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["train_kl_dds_d2", "train_kl_ei_gmm_d16", "train_kl_em_gmm_d16", "train_kl_dis_ei_d8", "train_kl_dis_orig_d8",
-                                  "train_kl_pis_phi4_d100"])
+                                  "train_kl_pis_phi4_d100", "train_kl_cmcd_gmm_d16"])
 def test_kl_training_loss_and_gradients_match_reference(gpu, name):
     """method='kl' -- BaseOCLoss's default, BASELINE cfg 1's loss: back-propagation through the whole trajectory (losses/oc.py:105-131).
     Fixtures: the reference's own ``loss(...)`` + ``backward()`` under the replayed noise.  Here: the HIP trajectory + the discrete
@@ -81,14 +81,16 @@ def test_kl_training_loss_and_gradients_match_reference(gpu, name):
 
 
 @pytest.mark.gpu
-def test_cmcd_kl_training_is_refused(gpu):
-    """The one KL path without an adjoint here: ControlledLangevinSDELoss (two control evaluations per step share the state)."""
+def test_sde_ctrl_noise_is_refused_in_training(gpu):
+    """What the training direction still refuses: a perturbed simulated control (sde_ctrl_noise / sde_ctrl_dropout, losses/oc.py:97-101)."""
     c = gc.load("train_lv_cmcd_gmm_d16")
     c.meta["kind"] = KINDS[c.meta["kind"]]
     b = bc.build(c, gpu)
-    b["loss"].method = "kl"
-    with pytest.raises(E.UnsupportedByEngine):
-        b["loss"](b["ts"], b["x0"], *b["args"], initial_log_prob=b["kwargs"]["initial_log_prob"])
+    b["loss"].sde_ctrl_noise = 0.1
+    for method in ("lv", "kl"):
+        b["loss"].method = method
+        with pytest.raises(E.UnsupportedByEngine):
+            b["loss"](b["ts"], b["x0"], *b["args"], initial_log_prob=b["kwargs"]["initial_log_prob"])
 
 
 @pytest.mark.gpu
