@@ -303,7 +303,9 @@ size_t sdeng_ctrl_vjp_workspace_bytes(int32_t d, int32_t n_times);
  * (FORM_LIN: alpha = c2, beta = 2 c4, gamma = c5, A = c1, C = c2;  FORM_EM: alpha = c2 c4, beta = c4, gamma = c5, A = 1 + c4 c1, C = c4 c3;
  * gamma = 0 without SDENG_FLAG_ITO) and writes the per-row arrays of sdeng_ctrl_vjp at row k * B + b: the parameter gradients are the same
  * six products.  Reads desc->{abi_version, B, d, N, form, flags & ITO, coef, net, ref (NONE / GAUSS_DIAG / GMM_DIAG), target, workspace}.
- * Controls: ClippedCtrl, and ScoreCtrl (models/reparam.py:63-117; BASELINE configs 1 and 3: DDS, PIS) on a diagonal mixture or phi^4 target
+ * Controls: ClippedCtrl, and ScoreCtrl / LerpCtrl / CancelDriftCtrl (models/reparam.py:63-199; the latter two with the per-step gains of
+ * coef[7], coef[8] and, for LerpCtrl, desc->prior = the IsotropicGauss whose score is interpolated: d lerp/dx = (1 - t/T)(-1/var) + (t/T) H_pi)
+ * -- written out for ScoreCtrl (BASELINE configs 1 and 3: DDS, PIS) -- on a diagonal mixture or phi^4 target
  * (desc->target of kind GMM_DIAG / PHI4): u = clip(net) + scale clip(score_pi(x)) s_theta(t); the state gradient gains
  * scale s_theta H_pi(x) (mask cot) (closed-form Hessian-vector product: mixture, or the lattice's tridiagonal Hessian; skipped with detach_score), and `dst` receives the cotangent of s_theta(t_k) per particle -- the caller sums
  * it over the particles and back-propagates the N values through the small score model. */

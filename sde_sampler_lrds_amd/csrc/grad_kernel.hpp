@@ -267,6 +267,8 @@ struct AdjArgs {
   const float* stheta;    // [N] clipped s_theta(t_k), or nullptr (no score model: 1)
   DistDev target;         // SDENG_DIST_GMM_DIAG tables (k_dist_tables), or the PHI4 constants
   float scale_score, clip_score;
+  int ctrl_kind;          // SDENG_CTRL_SCORE / _LERP / _CANCEL_DRIFT (per-step gains: coef cols 7, 8 as in the step loop, sim_kernel.hpp ctrl_score_term)
+  float prior_loc, prior_scale;  // LerpCtrl: the IsotropicGauss prior whose score is interpolated with the target's
   int score_detached;     // detach_score: the target score is a constant of x (no Hessian term in the state gradient)
   float* dst;             // [N * B] <cot, scale clip(score)>: the cotangent of s_theta(t_k), per particle
 };
@@ -379,6 +381,8 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
       const float c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4], c5 = cf[5];
       const float alpha = a.lin ? c2 : c2 * c4, beta = wb * (a.lin ? 2.0f * c4 : c4), gamma = a.noise ? wb * c5 : 0.0f;
       const float A = a.lin ? c1 : __builtin_fmaf(c4, c1, 1.0f), C = a.lin ? c2 : c4 * c3;
+      const float lerp_w = cf[8];  // LerpCtrl: t/T; CancelDriftCtrl: drift gain
+      const float inv_pvar = SCORE != ADJ_NONE ? 1.0f / (a.prior_scale * a.prior_scale) : 0.0f;
       const uint32_t row = static_cast<uint32_t>(k) * static_cast<uint32_t>(v.B) + b;
       f32x4 x[NT], gx[NT], jl[NT];
       load_rows<NT>(v.x, row, v.d, live, g, x);
@@ -393,7 +397,18 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
         asm volatile("" ::: "memory");
         if constexpr (SCORE == ADJ_GMM) gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, sr);
         else phi4_score<NT>(x, a.target, v.d, g, lane, sr);
-        gain_st = a.scale_score * (a.stheta ? a.stheta[k] : 1.0f);
+        // LerpCtrl (models/reparam.py:166-199): the score that is clipped and scaled is lerp(score_prior, score_pi, t/T), times g(t);
+        // CancelDriftCtrl (:120-145): + drift(t,x)/g(t) (linear in x, gain cf[8]) and the score part times g(t)/2 (cf[7])
+        if (a.ctrl_kind == SDENG_CTRL_LERP) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float ps = feat_live<NT>(t, r, 4 * g, v.d) ? (a.prior_loc - x[t][r]) * inv_pvar : 0.0f;
+              sr[t][r] = __builtin_fmaf(lerp_w, sr[t][r] - ps, ps);
+            }
+        }
+        gain_st = a.scale_score * (a.stheta ? a.stheta[k] : 1.0f) * (a.ctrl_kind == SDENG_CTRL_SCORE ? 1.0f : cf[7]);
       }
       vjp_tile<NT, true>(v, lds, lds_t, bias, ns, trash, row, live, v.temb + static_cast<size_t>(k) * SD_H, lane, x, true, true,
                          [&](int t, const f32x4& u) __attribute__((always_inline)) {
@@ -402,7 +417,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
 #pragma unroll
                            for (int r = 0; r < 4; ++r) {
                              float uv = u[r];
-                             if constexpr (SCORE != ADJ_NONE) uv = __builtin_fmaf(gain_st, a.clip_score > 0.0f ? clampf(sr[t][r], a.clip_score) : sr[t][r], uv);
+                             if constexpr (SCORE != ADJ_NONE) {
+                               uv = __builtin_fmaf(gain_st, a.clip_score > 0.0f ? clampf(sr[t][r], a.clip_score) : sr[t][r], uv);
+                               if (a.ctrl_kind == SDENG_CTRL_CANCEL_DRIFT && feat_live<NT>(t, r, 4 * g, v.d)) uv = __builtin_fmaf(lerp_w, x[t][r], uv);
+                             }
                              c[r] = __builtin_fmaf(alpha, lam[t][r], __builtin_fmaf(beta, uv, gamma * z[r]));
                            }
                            if constexpr (SCORE != ADJ_NONE) gfull[t] = c;
@@ -422,16 +440,28 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
             ds = __builtin_fmaf(gfull[t][r], a.clip_score > 0.0f ? clampf(sr[t][r], a.clip_score) : sr[t][r], ds);
             gm[t][r] = pass ? gfull[t][r] : 0.0f;
           }
-        ds = group_sum(ds) * a.scale_score;
+        ds = group_sum(ds) * (a.scale_score * (a.ctrl_kind == SDENG_CTRL_SCORE ? 1.0f : cf[7]));
         if (live && g == 0) a.dst[row] = ds;
         if (!a.score_detached) {
           asm volatile("" ::: "memory");
           if constexpr (SCORE == ADJ_GMM) gmm_hvp<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, gm, hv);
           else phi4_hvp<NT>(x, a.target, v.d, g, lane, gm, hv);
+          if (a.ctrl_kind == SDENG_CTRL_LERP) {  // d lerp / d x = (1 - w) (-1/var) + w H_pi
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) hv[t][r] = __builtin_fmaf(lerp_w, hv[t][r], (lerp_w - 1.0f) * inv_pvar * gm[t][r]);
+          }
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gx[t][r] = __builtin_fmaf(gain_st, hv[t][r], gx[t][r]);
+        }
+        if (a.ctrl_kind == SDENG_CTRL_CANCEL_DRIFT) {  // the drift/g term: lerp_w x on the live features
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gx[t][r] = feat_live<NT>(t, r, 4 * g, v.d) ? __builtin_fmaf(lerp_w, gfull[t][r], gx[t][r]) : gx[t][r];
         }
       }
 #pragma unroll

@@ -832,10 +832,12 @@ static int check_adjoint(const sdeng_desc* d) {
   if (d->abi_version != SDENG_ABI_VERSION) return fail(SDENG_E_INVALID, "ABI version %d, library has %d", d->abi_version, SDENG_ABI_VERSION);
   if (d->d < 1 || d->d > 128 || d->N < 1 || d->B < 1 || !d->coef) return fail(SDENG_E_INVALID, "bad sizes (1 <= d <= 128, N, B >= 1) or null coef");
   if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM) return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: forward forms LIN / EM (form %d)", d->form);
-  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED &&
-      !(d->net.ctrl_kind == SDENG_CTRL_SCORE && (d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_PHI4)))
-    return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: ClippedCtrl, or ScoreCtrl on a diagonal mixture / phi^4 target (ctrl_kind %d, target kind %d)",
-                d->net.ctrl_kind, d->target.kind);
+  const bool score_like = d->net.ctrl_kind == SDENG_CTRL_SCORE || d->net.ctrl_kind == SDENG_CTRL_LERP || d->net.ctrl_kind == SDENG_CTRL_CANCEL_DRIFT;
+  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && !(score_like && (d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_PHI4)))
+    return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: ClippedCtrl, or Score / Lerp / CancelDrift control on a diagonal mixture / phi^4 target (ctrl_kind %d, "
+                                     "target kind %d)", d->net.ctrl_kind, d->target.kind);
+  if (d->net.ctrl_kind == SDENG_CTRL_LERP && d->prior.kind != SDENG_DIST_ISO_GAUSS)
+    return fail(SDENG_E_UNSUPPORTED, "LerpCtrl needs an IsotropicGauss prior (kind %d given)", d->prior.kind);
   if (d->ref.kind != SDENG_REF_NONE && d->ref.kind != SDENG_REF_GAUSS_DIAG && d->ref.kind != SDENG_REF_GMM_DIAG)
     return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: no reference, or a diagonal Gaussian / mixture reference (ref.kind %d)", d->ref.kind);
   if (d->ref.kind != SDENG_REF_NONE && ((d->ref.kind == SDENG_REF_GMM_DIAG && d->ref.k < 1) || !d->ref.means_init || !d->ref.vars_init))
@@ -859,8 +861,8 @@ extern "C" int sdeng_kl_adjoint(const sdeng_desc* d, const sdeng_adjoint* adj, v
   const int DT = tiles_exact(d->d), dpad = 16 * DT;
   size_t o_wt, o_temb, o_trash, o_tab, o_consts, o_stheta, o_target;
   const size_t need = adjoint_floats(d, DT, &o_wt, &o_temb, &o_trash, &o_tab, &o_consts, &o_stheta, &o_target) * sizeof(float);
-  const bool score = d->net.ctrl_kind == SDENG_CTRL_SCORE;
-  if (score && !adj->dst) return fail(SDENG_E_INVALID, "kl_adjoint: ScoreCtrl needs the dst output");
+  const bool score = d->net.ctrl_kind != SDENG_CTRL_CLIPPED;
+  if (score && !adj->dst) return fail(SDENG_E_INVALID, "kl_adjoint: a score control needs the dst output");
   if (!d->workspace || d->workspace_bytes < need) return fail(SDENG_E_WORKSPACE, "workspace %zu bytes, need %zu", d->workspace_bytes, need);
   float* ws = static_cast<float*>(d->workspace);
   PackArgs pk;
@@ -903,6 +905,8 @@ extern "C" int sdeng_kl_adjoint(const sdeng_desc* d, const sdeng_adjoint* adj, v
     rc = build_dist(d->target, d->d, dpad, ws + o_target, a.target, s);
     if (rc) return rc;
     a.scale_score = d->net.scale_score; a.clip_score = d->net.clip_score;
+    a.ctrl_kind = d->net.ctrl_kind;
+    a.prior_loc = d->prior.p0; a.prior_scale = d->net.ctrl_kind == SDENG_CTRL_LERP ? d->prior.p1 : 1.0f;
     a.score_detached = adj->detach_score ? 1 : 0;
     a.dst = adj->dst;
   }

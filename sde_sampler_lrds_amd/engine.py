@@ -832,7 +832,9 @@ def adjoint_ctrl_ok(ctrl) -> bool:
         return False
     if name == "ClippedCtrl":
         return True
-    if name != "ScoreCtrl":
+    if name not in ("ScoreCtrl", "LerpCtrl", "CancelDriftCtrl"):
+        return False
+    if name == "LerpCtrl" and (getattr(ctrl, "hard_constrain", False) or _name(_self_of(ctrl.prior_score)) != "IsotropicGauss"):
         return False
     tgt = _self_of(ctrl.target_score)
     if tgt is None:
@@ -864,9 +866,12 @@ def kl_adjoint(ctrl, coef: torch.Tensor, xs: torch.Tensor, z, w: torch.Tensor, l
     desc.net = net_desc(ctrl, device, keep)
     if not adjoint_ctrl_ok(ctrl):
         raise UnsupportedByEngine("kl_adjoint: ClippedCtrl, or ScoreCtrl on a diagonal mixture target")
-    score = desc.net.ctrl_kind == L.CTRL_SCORE
+    score = desc.net.ctrl_kind != L.CTRL_CLIPPED
     if score:
-        desc.target = dist_desc(ctrl_target(ctrl)[0], device, keep)
+        tgt, lerp_prior = ctrl_target(ctrl)
+        desc.target = dist_desc(tgt, device, keep)
+        if lerp_prior is not None:
+            desc.prior = dist_desc(lerp_prior, device, keep)
     desc.ref = ref_desc(ref[0], ref[1], device, keep)
     if desc.ref.kind not in (L.REF_NONE, L.REF_GAUSS_DIAG, L.REF_GMM_DIAG):
         raise UnsupportedByEngine("kl_adjoint: diagonal references only")

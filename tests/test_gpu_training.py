@@ -301,6 +301,39 @@ def test_kl_training_native_adjoint_equals_the_stepwise_one(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver,ref,integ,mtype,details,ctrl_name", [
+    ("dis_orig", "default", "em", "target_informed_lerp_tempering", dict(sigma=1.0), "LerpCtrl"),
+    ("dis_orig", "default", "em", "target_informed_langevin_init", dict(sigma=1.0), "CancelDriftCtrl"),
+    ("pis_orig", "default", "em", "target_informed_zero_init", dict(sigma=0.4472135954999579), "ScoreCtrl"),
+    ("vp-ref", "default", "ei", "base_zero_init", dict(sigma=1.5), "ClippedCtrl"),
+    ("vp-ref", "gmm", "em", "base_zero_init", dict(means_ref=torch.tensor([[1.0] * 8, [-1.0] * 8]), variances_ref=0.5 * torch.ones(2, 8), weights_ref=torch.ones(2)), "ClippedCtrl")])
+def test_native_adjoint_equals_stepwise_for_every_control(gpu, solver, ref, integ, mtype, details, ctrl_name):
+    """make_model(...) with method='kl' for each control wrapper / reference kind the one-launch adjoint covers: same loss value, and every
+    gradient equal to the step-by-step adjoint's (torch vector-Jacobian products of the module itself, i.e. of the reference's formulas)."""
+    from sde_sampler_lrds_amd.experiments.benchmark_utils import make_model, make_target_details
+    tgt = make_target_details("many_modes", dim=8, n_modes=4)
+    out = {}
+    for native in (True, False):
+        torch.manual_seed(0)
+        model = make_model(solver, ref, "kl", integ, mtype, "uniform", details, tgt, dict(train_steps=2, train_batch_size=300, eval_batch_size=300),
+                           optim_details=dict(lr=1e-3), n_steps=24)
+        ctrl = model.loss.generative_ctrl
+        assert type(ctrl).__name__ == ctrl_name and E.adjoint_ctrl_ok(ctrl)
+        with torch.no_grad():
+            g = torch.Generator(device="cpu").manual_seed(1)
+            ctrl.base_model.out_layer.weight.copy_(0.05 * torch.randn(ctrl.base_model.out_layer.weight.shape, generator=g))
+        model.loss.native_adjoint = native
+        model.setup_optim()
+        loss, _ = model.compute_loss()
+        loss.backward()
+        out[native] = (float(loss.detach()), {k: p.grad.clone() for k, p in ctrl.named_parameters() if p.grad is not None})
+    assert out[True][0] == out[False][0] and out[True][1].keys() == out[False][1].keys()
+    worst = max(float((out[True][1][k] - g).abs().max() / g.abs().max().clamp(min=1e-30)) for k, g in out[False][1].items())
+    print(f"{solver} / {ctrl_name}: native vs stepwise adjoint, worst relative gradient difference {worst:.2e} over {len(out[False][1])} parameters")
+    assert worst < 2e-5
+
+
+@pytest.mark.gpu
 def test_kl_training_at_baseline_config_1_size(gpu):
     """BASELINE config 1 as the reference runs it (DDS on TwoModes d=2, KL loss, 4 096 particles x 64 steps, cosine time grid): the one-launch
     adjoint against the step-by-step one (torch vector-Jacobian products of the whole ScoreCtrl) on the SAME trajectory -- every gradient --

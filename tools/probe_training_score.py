@@ -31,3 +31,9 @@ for method in ("lv", "kl"):
     tgt = make_target_details("phi_four", dim=100)
     bench(f"PIS PhiFour d=100 512 x 128 [{method}]", make_model("pis_orig", "default", method, "em", "target_informed_zero_init", "uniform", dict(sigma=0.4472135954999579), tgt,
           dict(train_steps=10, train_batch_size=512, eval_batch_size=512), optim_details=dict(lr=1e-3), n_steps=128))
+for method in ("lv", "kl"):
+    tgt = make_target_details("many_modes", dim=16, n_modes=4)
+    bench(f"DIS (LerpCtrl) ManyModes d=16 2048 x 100 [{method}]", make_model("dis_orig", "default", method, "em", "target_informed_lerp_tempering", "uniform", dict(sigma=1.0), tgt,
+          dict(train_steps=10, train_batch_size=2048, eval_batch_size=2048), optim_details=dict(lr=1e-3), n_steps=100))
+    bench(f"CMCD ManyModes d=16 2048 x 100 [{method}]", make_model("cmcd", "default", method, "em", "target_informed_zero_init", "uniform", dict(), tgt,
+          dict(train_steps=10, train_batch_size=2048, eval_batch_size=2048), optim_details=dict(lr=1e-3), n_steps=100))
