@@ -311,6 +311,38 @@ SD_INLINE void mlp_hidden(const f32x4 (&x)[NT], f32x4 (&a)[SD_HT], const float* 
   gelu_tiles<SD_HT>(a);
 }
 
+// The same with the layer scales applied (NetScale: weight matrices stored times 2^e) -- for the step loops that carry no
+// range-safe twin (matrix-pipe / full-covariance mixture kernels, in-loop logistic regression: their own state products have none, and
+// the twin cost them 4.5 % in spills).  Exact power-of-two scalings, one uniform test per layer: a net whose scales are all 1 gives the
+// bits of mlp_hidden.
+template <int NT>
+SD_INLINE void mlp_hidden_scaled(const f32x4 (&x)[NT], f32x4 (&a)[SD_HT], const float* lds, const float* bias, const float* temb,
+                                 int lane, const NetScale& ns) {
+  const int g = lane >> 4;
+  f32x4 b[SD_HT];
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias, t, g);  // b_in 2^e
+  dense<NT, SD_HT>(x, a, lds + sd_off_win(NT), lane);
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) {
+    const f32x4 te = load_tile4(temb, t, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[t][r] = __builtin_fmaf(te[r], ns.s_in, a[t][r]);  // + embed_t 2^e  (s_in = 1: a + te bit for bit)
+  }
+  unscale_tiles<SD_HT>(a, ns.inv_in);
+  gelu_tiles<SD_HT>(a);
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) b[t] = load_tile4(bias + 64, t, g);  // b_h1
+  dense<SD_HT, SD_HT>(a, b, lds + sd_off_wh1(NT), lane);
+  unscale_tiles<SD_HT>(b, ns.inv_h1);
+  gelu_tiles<SD_HT>(b);
+#pragma unroll
+  for (int t = 0; t < SD_HT; ++t) a[t] = load_tile4(bias + 128, t, g);  // b_h2
+  dense<SD_HT, SD_HT>(b, a, lds + sd_off_wh2(NT), lane);
+  unscale_tiles<SD_HT>(a, ns.inv_h2);
+  gelu_tiles<SD_HT>(a);
+}
+
 // ----------------------------------------------------------------------------------------------
 // Range-safe twin of the drift net.  The split operands are f16: a state or an activation beyond 65 504 becomes inf there and the
 // step would return NaN where the reference (fp32 GEMMs) stays finite.  The step loop detects that after the fact -- one compare per

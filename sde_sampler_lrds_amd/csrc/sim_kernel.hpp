@@ -245,7 +245,12 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
       // -- hidden layers 2, the whole tail (output layer, noise, integrator) 1, scores and bookkeeping 0 -- are worth another 2.4 %
       // (4.74 -> 4.63, 15.22 -> 14.86): profiles/r02_issue_priority.log.
       __builtin_amdgcn_s_setprio(2);
-      mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
+      // (kernels whose reference / target score puts the state itself through split-f16 products -- matrix-pipe and full-covariance mixtures,
+      // the in-loop logistic-regression score -- carry no range-safe twin: those products have none, the guard would be half a guard;
+      // scaled weights are un-scaled layer by layer there)
+      constexpr bool has_twin = REF != RF_GMM_MM && REF != RF_GMM_FULL && SC != SC_LOGREG;
+      if constexpr (has_twin) mlp_hidden<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane);
+      else mlp_hidden_scaled<NT>(x, hid, lds, bias, a.temb + static_cast<size_t>(k) * SD_H, lane, ns);
       __builtin_amdgcn_s_setprio(1);
       HidSplit hs = split_hidden(hid);
       // The range-safe twin of the net (sim_device.hpp mlp_hidden_safe) takes over -- at the first output tile of the step, below --
@@ -493,16 +498,18 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
         f32x4 u[OT];
         // ONE copy of the output layer in the step loop: a step that went through the range-safe twin (below, first group) left the split
         // of hid * sigma in `hs`; the plain product then gives b 2^e + sigma 2^e W a, which out_tiles_unscale turns into (W a + b)
-        mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
-        if (__builtin_expect(safe_net, 0)) out_tiles_unscale<OT>(u, bias, t0, lane, hid_rs, ns.inv_out);
-        // (not in the kernels whose reference / target score puts the state itself through split-f16 products -- matrix-pipe and
-        // full-covariance mixtures, the in-loop logistic-regression score: those products have no twin, the guard would be half a guard)
+        if constexpr (has_twin) {
+          mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
+          if (__builtin_expect(safe_net, 0)) out_tiles_unscale<OT>(u, bias, t0, lane, hid_rs, ns.inv_out);
+        } else {
+          mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u, ns.inv_out);
+        }
 #ifdef SD_NO_RANGE_GUARD
         constexpr bool range_guard = false;
 #else
-        constexpr bool range_guard = REF != RF_GMM_MM && REF != RF_GMM_FULL && SC != SC_LOGREG;
+        constexpr bool range_guard = has_twin;
 #endif
-        if (t0 == 0) {
+        if (has_twin && t0 == 0) {
           // A state or an activation beyond f16's range (65 504) turned into inf in a split operand: every output of that particle is
           // then inf or NaN, so ONE compare on the first output register finds it.  The net of this step is evaluated again through
           // the range-safe twin (per-particle power-of-two scaling of every layer's input) -- x has not been touched yet.  The

@@ -158,3 +158,31 @@ def test_non_finite_inputs_stay_non_finite(gpu):
     ok = torch.ones(B, dtype=torch.bool)
     ok[[5, 20]] = False
     assert bool(torch.isfinite(x[ok.to(gpu)]).all()) and bool(torch.isfinite(rnd[ok.to(gpu)]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rds_ei_gmm_d128_k16", "rds_ei_gmm_fullcov_d128_k4", "pis_gmm_full_d128_k3", "pis_logreg_d61"])
+def test_scaled_weights_in_the_step_loops_without_a_twin(gpu, name):
+    """The matrix-pipe / full-covariance mixture kernels and the in-loop logistic-regression control carry no range-safe twin: scaled weight
+    matrices are un-scaled layer by layer there (mlp_hidden_scaled).  The fixture's net with its input layer x 1e-5 and its second hidden
+    layer x 2e-4 (entries below 2^-10: both stored scaled up), the output weights x 5e3 so that the control keeps its size (activations
+    stay inside f16's range: these kernels have no overflow twin): injected noise, x_N and the log-weights against the ORACLE run on
+    the same modified net."""
+    from tests import build_cases as bc
+    from tests import golden_cases as gc
+    from tests.test_gpu_parity import TOL, replay_noise, rnd_scale, sensitivity
+    c = gc.load(name)
+    for key, f in (("input_embed.weight", 1e-5), ("input_embed.bias", 1e-5), ("hidden_layer.1.weight", 2e-4), ("hidden_layer.1.bias", 2e-4),
+                   ("out_layer.weight", 5e3)):
+        c.a["ctrl.base_model." + key] = c.a["ctrl.base_model." + key] * f
+    noise = replay_noise(c)
+    x_o, r_o = gc.run_oracle(c)
+    b = bc.build(c, gpu)
+    x, rnd, _ = b["loss"].simulate(b["ts"], b["x0"], *b["args"], noise=noise.to(gpu), **b["kwargs"])
+    torch.cuda.synchronize()
+    c.a["out_x"], c.a["rnd"] = x_o, r_o  # (rnd_scale reads the case's own outputs)
+    ex = gc.rel_err(x.cpu(), x_o)
+    er = float(((rnd.cpu().double() - r_o.double()).abs() / rnd_scale(c).double()).max())
+    tol = max(TOL, 10 * sensitivity(name))
+    print(f"{name} with scaled layers: x_N {ex:.2e}, rnd {er:.2e} against the oracle (tolerance {tol:.1e})")
+    assert bool(torch.isfinite(x).all()) and ex < tol and er < tol
