@@ -269,6 +269,7 @@ SD_INLINE void gelu_tiles(f32x4 (&v)[T]) {
 struct NetScale {
   float inv_in, inv_h1, inv_h2, inv_out, s_in;
   SD_INLINE bool any() const { return (inv_in != 1.0f) | (inv_h1 != 1.0f) | (inv_h2 != 1.0f) | (inv_out != 1.0f); }
+  SD_INLINE bool any_hidden() const { return (inv_in != 1.0f) | (inv_h1 != 1.0f) | (inv_h2 != 1.0f); }  // (the output layer is linear: un-scaled where it is produced)
 };
 SD_INLINE NetScale load_net_scale(const float* bias, int NT) {
   const float* sc = bias + 3 * 64 + 16 * NT;  // uniform address: scalar loads, loop invariant

@@ -140,8 +140,12 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
 #ifdef SD_NO_RANGE_GUARD  // A/B builds only (tools/variant_lib.sh): the step loop without the range guard of DESIGN 4b
   const bool scaled_net = false;
 #else
-  const bool scaled_net = ns.any();
+  // Only scaled INPUT / HIDDEN layers send a net through the twin; a scaled OUTPUT layer -- the state of every freshly initialised
+  // make_model, |w| <= 1.25e-7 -- is un-scaled where the plain output tiles are produced (one uniform test per tile group): before this
+  // such a net ran plain pass + twin every step (cfg 2 4.8 -> 7.8 ms, cfg 3 15.6 -> 26.8 ms, profiles/r03_scaled_net.log).
+  const bool scaled_net = ns.any_hidden();
 #endif
+  const float inv_out_plain = ns.inv_out;
   // this wave's private copy of the current step's reference table (Gaussian / small-mixture references)
 #ifdef SD_DBG_NODMA
   constexpr bool ref_lds = false;
@@ -266,7 +270,13 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
         if (NT == 1 && a.target.kind == SDENG_DIST_RINGS) ts[0] = rings_score(x[0], a.target, g);
         else gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, ts);
       }
-      if constexpr (SC == SC_PHI4) phi4_score<NT>(x, a.target, d_dyn, g, lane, ts);
+      if constexpr (SC == SC_PHI4) {
+        // (eight feature tiles at three waves per SIMD: the neighbour-lane indices of the lattice score, left loop-invariant, are parked in
+        // scratch and reloaded every step; derived from an opaque copy of the lane id they are two integer instructions next to their use)
+        int lane_p = lane;
+        if constexpr (NT == 8) asm volatile("" : "+v"(lane_p));
+        phi4_score<NT>(x, a.target, d_dyn, g, lane_p, ts);
+      }
       if constexpr (SC == SC_LOGREG) {
         asm volatile("" ::: "memory");
         f16x8 xh[(NT + 1) / 2], xl[(NT + 1) / 2];
@@ -501,6 +511,10 @@ __global__ void __launch_bounds__((64 * sd_waves_of<NT, REF, SC, FORM, PAR>()), 
         if constexpr (has_twin) {
           mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u);
           if (__builtin_expect(safe_net, 0)) out_tiles_unscale<OT>(u, bias, t0, lane, hid_rs, ns.inv_out);
+          else if (__builtin_expect(inv_out_plain != 1.0f, 0)) {
+#pragma unroll
+            for (int o = 0; o < OT; ++o) u[o] = u[o] * inv_out_plain;
+          }
         } else {
           mlp_out_tiles<NT, OT>(hs, lds, bias, t0, lane, u, ns.inv_out);
         }
