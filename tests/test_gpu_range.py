@@ -161,9 +161,36 @@ def test_non_finite_inputs_stay_non_finite(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["rds_ei_gmm_d128_k16", "rds_ei_gmm_fullcov_d128_k4", "pis_gmm_full_d128_k3", "pis_logreg_d61"])
+@pytest.mark.parametrize("name", ["rds_ei_gmm_d128_k4", "pis_em_phi4_d100", "cmcd_logreg_d61", "rds_em_gmm_d16", "dds_two_modes_d2", "rds_ei_gmm_d128_k16"])
+def test_step_loop_at_the_default_initialisation_magnitude(gpu, name):
+    """Every freshly built model starts with its last layer at |w| <= 1.25e-7 (models/utils.py:7-22): stored scaled up, un-scaled where the
+    output tiles are produced (the plain path of the step loop, not the twin).  The fixture's net with its output layer x 1e-6, injected
+    noise: x_N and the log-weights against the ORACLE on the same net."""
+    from tests import build_cases as bc
+    from tests import golden_cases as gc
+    from tests.test_gpu_parity import TOL, replay_noise, rnd_scale, sensitivity
+    c = gc.load(name)
+    for key in ("out_layer.weight", "out_layer.bias"):
+        c.a["ctrl.base_model." + key] = c.a["ctrl.base_model." + key] * 1e-6
+    noise = replay_noise(c)
+    x_o, r_o = gc.run_oracle(c)
+    b = bc.build(c, gpu)
+    x, rnd, _ = b["loss"].simulate(b["ts"], b["x0"], *b["args"], noise=noise.to(gpu), **b["kwargs"])
+    torch.cuda.synchronize()
+    c.a["out_x"], c.a["rnd"] = x_o, r_o
+    ex = gc.rel_err(x.cpu(), x_o)
+    er = float(((rnd.cpu().double() - r_o.double()).abs() / rnd_scale(c).double()).max())
+    tol = max(TOL, 10 * sensitivity(name))
+    print(f"{name} with the output layer x 1e-6: x_N {ex:.2e}, rnd {er:.2e} against the oracle (tolerance {tol:.1e})")
+    assert bool(torch.isfinite(x).all()) and ex < tol and er < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rds_ei_gmm_d128_k16", "rds_ei_gmm_fullcov_d128_k4", "pis_gmm_full_d128_k3", "pis_logreg_d61", "rds_ei_gmm_d128_k4",
+                                  "pis_em_phi4_d100"])
 def test_scaled_weights_in_the_step_loops_without_a_twin(gpu, name):
-    """The matrix-pipe / full-covariance mixture kernels and the in-loop logistic-regression control carry no range-safe twin: scaled weight
+    """(the last two names: standard kernels, where scaled input / hidden layers go through the twin instead)
+    The matrix-pipe / full-covariance mixture kernels and the in-loop logistic-regression control carry no range-safe twin: scaled weight
     matrices are un-scaled layer by layer there (mlp_hidden_scaled).  The fixture's net with its input layer x 1e-5 and its second hidden
     layer x 2e-4 (entries below 2^-10: both stored scaled up), the output weights x 5e3 so that the control keeps its size (activations
     stay inside f16's range: these kernels have no overflow twin): injected noise, x_N and the log-weights against the ORACLE run on
