@@ -278,7 +278,8 @@ SD_INLINE NetScale load_net_scale(const float* bias, int NT) {
 // layer output *= 2^-e, behind ONE uniform test per layer (a multiply per element would cost the common case ~2 % for nothing)
 template <int T>
 SD_INLINE void unscale_tiles(f32x4 (&v)[T], float inv) {
-  if (inv != 1.0f) {
+  if (__builtin_expect(inv != 1.0f, 0)) {
+    asm volatile("" ::: "memory");  // keeps the test a branch: x * 1.0 = x, so the compiler otherwise drops it and multiplies every time
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = v[t] * inv;
   }
