@@ -319,6 +319,9 @@ typedef struct sdeng_adjoint {
   float* dout;          /* [N*B][d]                                                                          */
   float* dst;           /* [N*B] ScoreCtrl: <cot, scale clip(score_pi)>, the cotangent of s_theta(t_k) per particle; else NULL */
   int32_t detach_score; /* ScoreCtrl(detach_score=True): the target score is treated as a constant of x     */
+  const float* score;   /* [N*B][d] or NULL.  Given: the target score of every row, evaluated by the caller (sdeng_dist_eval) and treated as
+                           a constant of x -- for targets whose score the reference makes by autograd without a graph (distr/base.py:146-154:
+                           LogisticRegression), desc->target is then ignored */
 } sdeng_adjoint;
 int sdeng_kl_adjoint(const sdeng_desc* desc, const sdeng_adjoint* adj, void* stream);
 size_t sdeng_kl_adjoint_workspace_bytes(const sdeng_desc* desc);

@@ -47,7 +47,7 @@ class Ref(C.Structure):
 
 class Adjoint(C.Structure):  # sdeng_adjoint (include/sdeng.h)
     _fields_ = [(n, C.c_void_p) for n in ("xs", "noise", "w", "lam_in", "lam_out", "a0", "a1", "a2", "d0", "d1", "d2", "dout", "dst")] + [
-        ("detach_score", C.c_int32)]
+        ("detach_score", C.c_int32), ("score", C.c_void_p)]
 
 
 class Desc(C.Structure):

@@ -271,6 +271,7 @@ struct AdjArgs {
   float prior_loc, prior_scale;  // LerpCtrl: the IsotropicGauss prior whose score is interpolated with the target's
   int score_detached;     // detach_score: the target score is a constant of x (no Hessian term in the state gradient)
   float* dst;             // [N * B] <cot, scale clip(score)>: the cotangent of s_theta(t_k), per particle
+  const float* score_ext; // ADJ_EXT: [N * B, d] target score of every row
 };
 
 // H(x) lam for a diagonal Gaussian mixture (K = 1: a Gaussian): with q_k = (x - m_k)/var_k, p = softmax of the component logits, qbar = sum p_k q_k,
@@ -355,7 +356,10 @@ SD_INLINE void phi4_hvp(const f32x4 (&x)[NT], const DistDev& ds, int d, int g, i
   }
 }
 
-enum { ADJ_NONE = 0, ADJ_GMM = 1, ADJ_PHI4 = 2 };  // target of the ScoreCtrl the adjoint differentiates (0: ClippedCtrl)
+// target of the score control the adjoint differentiates (0: ClippedCtrl).  ADJ_EXT: the target score of every row is an INPUT (one
+// sdeng_dist_eval launch over all rows) and a constant of x -- targets whose score the reference makes with autograd and without a graph
+// (Distribution.score, distr/base.py:146-154: logistic regression), so that backward() sees no Hessian term either
+enum { ADJ_NONE = 0, ADJ_GMM = 1, ADJ_PHI4 = 2, ADJ_EXT = 3 };
 template <int NT, int SCORE>
 __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const AdjArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -396,7 +400,11 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
       if constexpr (SCORE != ADJ_NONE) {
         asm volatile("" ::: "memory");
         if constexpr (SCORE == ADJ_GMM) gmm_score<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, sr);
-        else phi4_score<NT>(x, a.target, v.d, g, lane, sr);
+        else if constexpr (SCORE == ADJ_PHI4) phi4_score<NT>(x, a.target, v.d, g, lane, sr);
+        else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) sr[t] = load_quad(a.score_ext, row, v.d, live, t, g);
+        }
         // LerpCtrl (models/reparam.py:166-199): the score that is clipped and scaled is lerp(score_prior, score_pi, t/T), times g(t);
         // CancelDriftCtrl (:120-145): + drift(t,x)/g(t) (linear in x, gain cf[8]) and the score part times g(t)/2 (cf[7])
         if (a.ctrl_kind == SDENG_CTRL_LERP) {
@@ -442,10 +450,10 @@ __global__ void __launch_bounds__(SD_THREADS, SD_WAVES / 4) k_kl_adjoint(const A
           }
         ds = group_sum(ds) * (a.scale_score * (a.ctrl_kind == SDENG_CTRL_SCORE ? 1.0f : cf[7]));
         if (live && g == 0) a.dst[row] = ds;
-        if (!a.score_detached) {
+        if (SCORE != ADJ_EXT && !a.score_detached) {
           asm volatile("" ::: "memory");
           if constexpr (SCORE == ADJ_GMM) gmm_hvp<NT>(x, a.target.tab, a.target.consts, 4, a.target.k, a.target.p0, g, gm, hv);
-          else phi4_hvp<NT>(x, a.target, v.d, g, lane, gm, hv);
+          else if constexpr (SCORE == ADJ_PHI4) phi4_hvp<NT>(x, a.target, v.d, g, lane, gm, hv);
           if (a.ctrl_kind == SDENG_CTRL_LERP) {  // d lerp / d x = (1 - w) (-1/var) + w H_pi
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -504,6 +512,7 @@ template <int NT>
 static int launch_kl_adjoint(const AdjArgs& a, int grid, hipStream_t stream) {
   if (a.has_score == ADJ_GMM) return launch_kl_adjoint_s<NT, ADJ_GMM>(a, grid, stream);
   if (a.has_score == ADJ_PHI4) return launch_kl_adjoint_s<NT, ADJ_PHI4>(a, grid, stream);
+  if (a.has_score == ADJ_EXT) return launch_kl_adjoint_s<NT, ADJ_EXT>(a, grid, stream);
   return launch_kl_adjoint_s<NT, ADJ_NONE>(a, grid, stream);
 }
 #define SD_DEFINE_VJP(NT) \

@@ -827,13 +827,13 @@ static size_t adjoint_floats(const sdeng_desc* d, int DT, size_t* o_wt, size_t* 
   *o_target = o; o += dist_floats(d->target, 16 * DT);
   return o;
 }
-static int check_adjoint(const sdeng_desc* d) {
+static int check_adjoint(const sdeng_desc* d, bool ext_score) {
   if (!d) return fail(SDENG_E_INVALID, "null descriptor");
   if (d->abi_version != SDENG_ABI_VERSION) return fail(SDENG_E_INVALID, "ABI version %d, library has %d", d->abi_version, SDENG_ABI_VERSION);
   if (d->d < 1 || d->d > 128 || d->N < 1 || d->B < 1 || !d->coef) return fail(SDENG_E_INVALID, "bad sizes (1 <= d <= 128, N, B >= 1) or null coef");
   if (d->form != SDENG_FORM_LIN && d->form != SDENG_FORM_EM) return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: forward forms LIN / EM (form %d)", d->form);
   const bool score_like = d->net.ctrl_kind == SDENG_CTRL_SCORE || d->net.ctrl_kind == SDENG_CTRL_LERP || d->net.ctrl_kind == SDENG_CTRL_CANCEL_DRIFT;
-  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && !(score_like && (d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_PHI4)))
+  if (d->net.ctrl_kind != SDENG_CTRL_CLIPPED && !(score_like && (ext_score || d->target.kind == SDENG_DIST_GMM_DIAG || d->target.kind == SDENG_DIST_PHI4)))
     return fail(SDENG_E_UNSUPPORTED, "kl_adjoint: ClippedCtrl, or Score / Lerp / CancelDrift control on a diagonal mixture / phi^4 target (ctrl_kind %d, "
                                      "target kind %d)", d->net.ctrl_kind, d->target.kind);
   if (d->net.ctrl_kind == SDENG_CTRL_LERP && d->prior.kind != SDENG_DIST_ISO_GAUSS)
@@ -852,7 +852,7 @@ extern "C" size_t sdeng_kl_adjoint_workspace_bytes(const sdeng_desc* d) {
 }
 extern "C" int sdeng_kl_adjoint(const sdeng_desc* d, const sdeng_adjoint* adj, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc = check_adjoint(d);
+  int rc = check_adjoint(d, adj && adj->score);
   if (rc) return rc;
   if (!adj || !adj->xs || !adj->w || !adj->lam_in || !adj->a0 || !adj->a1 || !adj->a2 || !adj->d0 || !adj->d1 || !adj->d2 || !adj->dout)
     return fail(SDENG_E_INVALID, "kl_adjoint: null states / weights / lambda_N / per-row outputs");
@@ -893,7 +893,8 @@ extern "C" int sdeng_kl_adjoint(const sdeng_desc* d, const sdeng_adjoint* adj, v
     a.ref_c1 = static_cast<float>(0.5 * d->d * std::log(2.0 * M_PI));
   }
   if (score) {
-    a.has_score = d->target.kind == SDENG_DIST_PHI4 ? 2 : 1;  // grad_kernel.hpp ADJ_PHI4 / ADJ_GMM
+    a.has_score = adj->score ? 3 : (d->target.kind == SDENG_DIST_PHI4 ? 2 : 1);  // grad_kernel.hpp ADJ_EXT / ADJ_PHI4 / ADJ_GMM
+    a.score_ext = adj->score;
     if (d->net.score_model.n_hidden > 0) {
       TimeEmbedArgs sm;
       sm.te = d->net.score_model; sm.coef = d->coef; sm.col = 0; sm.t_direct = 0; sm.t_value = 0.0f;
@@ -902,8 +903,10 @@ extern "C" int sdeng_kl_adjoint(const sdeng_desc* d, const sdeng_adjoint* adj, v
       SD_HIP(sd_launch_time_embed(sm, d->N, s));
       a.stheta = sm.out;
     }
-    rc = build_dist(d->target, d->d, dpad, ws + o_target, a.target, s);
-    if (rc) return rc;
+    if (!adj->score) {
+      rc = build_dist(d->target, d->d, dpad, ws + o_target, a.target, s);
+      if (rc) return rc;
+    }
     a.scale_score = d->net.scale_score; a.clip_score = d->net.clip_score;
     a.ctrl_kind = d->net.ctrl_kind;
     a.prior_loc = d->prior.p0; a.prior_scale = d->net.ctrl_kind == SDENG_CTRL_LERP ? d->prior.p1 : 1.0f;

@@ -824,6 +824,11 @@ def diagonal_reference(kind, utils) -> bool:
     return False
 
 
+# targets whose ``score`` is the base class's autograd evaluation WITHOUT a graph (distr/base.py:146-154): back-propagation through the
+# trajectory sees it as a constant of x, in the reference and here
+_GRAPHLESS_SCORE = ("LogisticRegression", "SyntheticLogReg")
+
+
 def adjoint_ctrl_ok(ctrl) -> bool:
     """Does sdeng_kl_adjoint differentiate this control?  ClippedCtrl over a FourierMLP, or a plain ScoreCtrl over one whose target is a
     diagonal mixture or the phi^4 lattice (BASELINE configs 1 and 3: DDS on TwoModes, PIS on PhiFour) and whose score model, if any, is a TimeEmbed."""
@@ -844,6 +849,8 @@ def adjoint_ctrl_ok(ctrl) -> bool:
             dist_desc(tgt, "cpu", [])  # (the 1-D Dirichlet-0 untilted lattice only)
         except UnsupportedByEngine:
             return False
+    elif _name(tgt) in _GRAPHLESS_SCORE:
+        pass  # the score of every row comes from the HIP score kernel and is a constant of x, as upstream's autograd-made score is
     elif _name(tgt) not in ("GMM", "TwoModes", "ManyModes", "BracketTwoModes") or getattr(tgt, "mixture_weights", None) is None:
         return False
     return ctrl.score_model is None or _name(ctrl.score_model) == "TimeEmbed"
@@ -867,9 +874,13 @@ def kl_adjoint(ctrl, coef: torch.Tensor, xs: torch.Tensor, z, w: torch.Tensor, l
     if not adjoint_ctrl_ok(ctrl):
         raise UnsupportedByEngine("kl_adjoint: ClippedCtrl, or ScoreCtrl on a diagonal mixture target")
     score = desc.net.ctrl_kind != L.CTRL_CLIPPED
+    ext_score = None
     if score:
         tgt, lerp_prior = ctrl_target(ctrl)
-        desc.target = dist_desc(tgt, device, keep)
+        if _name(tgt) in _GRAPHLESS_SCORE:
+            _, ext_score = dist_eval(tgt, xs.reshape(N * B, d), want_logp=False, want_score=True)
+        else:
+            desc.target = dist_desc(tgt, device, keep)
         if lerp_prior is not None:
             desc.prior = dist_desc(lerp_prior, device, keep)
     desc.ref = ref_desc(ref[0], ref[1], device, keep)
@@ -893,6 +904,7 @@ def kl_adjoint(ctrl, coef: torch.Tensor, xs: torch.Tensor, z, w: torch.Tensor, l
     dst = torch.empty(N, B, dtype=torch.float32, device=device) if score else None
     if score:
         adj.dst, adj.detach_score = dst.data_ptr(), int(bool(ctrl.detach_score))
+        adj.score = ext_score.data_ptr() if ext_score is not None else None
     L.check(lib.sdeng_kl_adjoint(C.byref(desc), C.byref(adj), _stream_ptr(device)))
     return dict(x=x, a0=hid[0], a1=hid[1], a2=hid[2], d0=hid[3], d1=hid[4], d2=hid[5], dout=dout, gx=None, dst=dst), lam0
 

@@ -357,3 +357,27 @@ def test_kl_training_at_baseline_config_1_size(gpu):
     worst = max(float((grads[True][1][k] - g).abs().max() / g.abs().max().clamp(min=1e-30)) for k, g in grads[False][1].items())
     print(f"cfg 1 size: native vs stepwise adjoint, worst relative gradient difference {worst:.2e} over {len(grads[False][1])} parameters")
     assert len(grads[False][1]) >= 20 and worst < 2e-4  # (the reference's own conditioning on this target: 1e-4, fixture train_kl_dds_d2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pis_logreg_d61", "dds_logreg_d61"])
+def test_native_adjoint_on_logistic_regression_targets(gpu, name):
+    """PIS / DDS on a Bayesian logistic-regression target with method='kl': the reference's LogisticRegression.score is autograd-made without a
+    graph (distr/base.py:146-154), so back-propagation sees it as a constant of x -- the one-launch adjoint takes the scores of all rows from
+    the HIP score kernel as an input (ADJ_EXT) and must give the step-by-step adjoint's gradients (torch VJPs of the module itself)."""
+    c = gc.load(name)
+    out = {}
+    for native in (True, False):
+        b = bc.build(c, gpu)
+        loss = b["loss"]
+        loss.method, loss.max_rnd, loss.native_adjoint = "kl", None, native
+        loss.seed = c.meta["seed"]
+        assert E.adjoint_ctrl_ok(loss.generative_ctrl)
+        kw = {k: v for k, v in b["kwargs"].items() if k == "initial_log_prob"}
+        value, _ = loss(b["ts"], b["x0"], *b["args"], **kw)
+        value.backward()
+        out[native] = (float(value.detach()), {k: p.grad.clone() for k, p in loss.generative_ctrl.named_parameters() if p.grad is not None})
+    assert out[True][0] == out[False][0] and out[True][1].keys() == out[False][1].keys()
+    worst = max(float((out[True][1][k] - g).abs().max() / g.abs().max().clamp(min=1e-30)) for k, g in out[False][1].items())
+    print(f"{name}: native (external score) vs stepwise adjoint, worst relative gradient difference {worst:.2e} over {len(out[False][1])} parameters")
+    assert len(out[False][1]) >= 20 and worst < 2e-5
