@@ -196,6 +196,7 @@ class BaseOCLoss:
         self._coef_cache = {}
         self._cpu_sde = None
         self.timing_events = None  # optional _lib.HipEvents: times the step-loop kernel alone
+        self.graph_adjoint = True  # KL training where the adjoint runs step by step in torch (CMCD; controls / targets / references the adjoint kernel does not cover): each step replayed as a hipGraph; False: eager
         self.native_adjoint = True  # KL training of a ClippedCtrl with no / a diagonal reference: the adjoint recursion as ONE launch (sdeng_kl_adjoint); False: one sdeng_ctrl_vjp per step
         self.fused_training = True  # ClippedCtrl over a FourierMLP: the batched control pass of training as ONE fused HIP forward + backward (sdeng_ctrl_vjp); False: the eager torch pass
         self.graph_training = False  # True: the batched control pass of log-variance training (forward + backward) is replayed as a hipGraph (_IntegralPass)
@@ -419,24 +420,35 @@ class BaseOCLoss:
                         lam = (1.0 + c[4] * c[1]) * lam + gx if jl is None else (1.0 + c[4] * c[1]) * lam + (c[4] * c[3]) * jl + gx
                 found = vjp_param_grads(ctrl, coef[:, 0].contiguous(), sess.arrays(), N, B)
                 grads = [found.get(p, torch.zeros_like(p)) for p in params]
-            for k in (range(N - 1, -1, -1) if not (fused or native) else ()):
-                c = coef[k]
-                xk = xs[k].detach().requires_grad_(True)
-                u = ctrl(c[0], xk)
-                ref = reference_ctrl(c[0], xk) if reference_ctrl is not None else None
-                uu, uz = (u * u).sum(-1, keepdim=True), (u * z[k]).sum(-1, keepdim=True)
-                if lin:   # x' = c1 x + c2 (u [+ ref]) + c3 z ;  rnd += c4 <u,u> + c5 <u,z>
-                    x_next = c[1] * xk + c[2] * (u if ref is None else ref + u) + c[3] * z[k]
-                    dr = c[4] * uu + (c[5] * uz if ito else 0.0)
-                else:     # x' = x + ((c1 x [+ c3 ref]) + c2 u) c4 + c2 (c5 z) ;  rnd += 0.5 <u,u> c4 + c5 <u,z>
-                    drift = c[1] * xk if ref is None else c[1] * xk + c[3] * ref
-                    x_next = xk + (drift + c[2] * u) * c[4] + c[2] * (c[5] * z[k])
-                    dr = 0.5 * uu * c[4] + (c[5] * uz if ito else 0.0)
-                got = torch.autograd.grad((lam * x_next).sum() + (w * dr).sum(), [xk] + params, allow_unused=True)
-                lam = got[0]
-                for acc, g in zip(grads, got[1:]):
-                    if g is not None:
-                        acc += g
+            def step(lam_in, x_in, z_in, c, w_in):
+                """One step of the adjoint in torch (controls / targets / references the adjoint kernel does not cover)."""
+                with torch.enable_grad():
+                    xk = x_in.detach().requires_grad_(True)
+                    u = ctrl(c[0], xk)
+                    ref = reference_ctrl(c[0], xk) if reference_ctrl is not None else None
+                    uu, uz = (u * u).sum(-1, keepdim=True), (u * z_in).sum(-1, keepdim=True)
+                    if lin:   # x' = c1 x + c2 (u [+ ref]) + c3 z ;  rnd += c4 <u,u> + c5 <u,z>
+                        x_next = c[1] * xk + c[2] * (u if ref is None else ref + u) + c[3] * z_in
+                        dr = c[4] * uu + (c[5] * uz if ito else 0.0)
+                    else:     # x' = x + ((c1 x [+ c3 ref]) + c2 u) c4 + c2 (c5 z) ;  rnd += 0.5 <u,u> c4 + c5 <u,z>
+                        drift = c[1] * xk if ref is None else c[1] * xk + c[3] * ref
+                        x_next = xk + (drift + c[2] * u) * c[4] + c[2] * (c[5] * z_in)
+                        dr = 0.5 * uu * c[4] + (c[5] * uz if ito else 0.0)
+                    got = torch.autograd.grad((lam_in * x_next).sum() + (w_in * dr).sum(), [xk] + params, allow_unused=True)
+                for acc, gk in zip(grads, got[1:]):
+                    if gk is not None:
+                        acc.add_(gk)
+                return got[0]
+
+            if not (fused or native):
+                # launch-bound (~60 small kernels per step): replayed as a hipGraph per (shape, control, form); eager if capture fails
+                runner = _graphed_step(self, ("kl", id(ctrl), id(getattr(reference_ctrl, "__self__", reference_ctrl)), B, d, bool(lin), bool(ito), str(x.device)), step, grads,
+                                            (lam, xs[0], z[0], coef[0], w)) if (self.graph_adjoint and _capturable(ctrl)) else None
+                for k in range(N - 1, -1, -1):
+                    args = (lam, xs[k], z[k], coef[k], w)
+                    lam = runner(*args) if runner is not None else step(*args)
+                if runner is not None:
+                    grads = [gr.clone() for gr in runner.grads]
         # hand the gradient to autograd: value + sum <p - p.detach(), dL/dp>  (zero-valued, gradient dL/dp)
         surrogate = sum(((p - p.detach()) * g).sum() for p, g in zip(params, grads))
         return value.detach() + surrogate, {"train/n_filtered_cumulative": self.n_filtered}
@@ -836,25 +848,110 @@ class ControlledLangevinSDELoss(_InitialLogProbLoss):
         grads = [torch.zeros_like(p) for p in params]
         g = self.sde.diff_coeff
         tdev = ts.to(x.device)
-        with torch.enable_grad():
-            xN = x_n.detach().requires_grad_(True)
-            lam, = torch.autograd.grad((w * (-terminal_unnorm_log_prob(xN).view(B, 1))).sum(), xN)
-            for k in range(N - 1, -1, -1):
-                s, t = tdev[k], tdev[k + 1]
+        def step(lam_in, x_in, z_in, s, t, w_in):
+            """One step of the adjoint: lambda_k and the parameter-gradient contributions of step k (accumulated into ``grads``)."""
+            with torch.enable_grad():
                 dt = t - s
-                db = dt.sqrt() * z[k]
-                xk = xs[k].detach().requires_grad_(True)
+                db = dt.sqrt() * z_in
+                xk = x_in.detach().requires_grad_(True)
                 u_s, b_s = ctrl(s, xk), self.sde.drift(s, xk)
                 y = xk + (b_s + u_s * g) * dt + g * db
                 cost = (b_s + self.sde.drift(t, y)) / g + u_s - ctrl(t, y)
                 dr = 0.5 * (cost ** 2).sum(-1, keepdim=True) * dt + (cost * db).sum(-1, keepdim=True)
-                got = torch.autograd.grad((lam * y).sum() + (w * dr).sum(), [xk] + params, allow_unused=True)
-                lam = got[0]
-                for acc, gk in zip(grads, got[1:]):
-                    if gk is not None:
-                        acc += gk
+                got = torch.autograd.grad((lam_in * y).sum() + (w_in * dr).sum(), [xk] + params, allow_unused=True)
+            for acc, gk in zip(grads, got[1:]):
+                if gk is not None:
+                    acc.add_(gk)
+            return got[0]
+
+        with torch.enable_grad():
+            xN = x_n.detach().requires_grad_(True)
+            lam, = torch.autograd.grad((w * (-terminal_unnorm_log_prob(xN).view(B, 1))).sum(), xN)
+        # The ~130 small kernels of one step are launch-bound (2048 x 100: 5 ms per step of the recursion): the step is captured once per
+        # (shape, control) as a hipGraph and replayed N times; a capture that fails runs the steps eagerly, and says so.
+        runner = _graphed_step(self, ("cmcd", id(ctrl), B, d, str(x.device)), step, grads,
+                                    (lam, xs[0], z[0], tdev[0], tdev[1], w)) if (self.graph_adjoint and _capturable(ctrl, self.sde.target_score)) else None
+        for k in range(N - 1, -1, -1):
+            args = (lam, xs[k], z[k], tdev[k], tdev[k + 1], w)
+            lam = runner(*args) if runner is not None else step(*args)
+        if runner is not None:
+            grads = [gr.clone() for gr in runner.grads]
         surrogate = sum(((p - p.detach()) * gr).sum() for p, gr in zip(params, grads))
         return value.detach() + surrogate, {"train/n_filtered_cumulative": self.n_filtered}
+
+
+
+def _capturable(ctrl, *score_fns) -> bool:
+    """Can one adjoint step of this control be captured as a hipGraph?  Not when a score in it is the base class's autograd evaluation
+    (distr/base.py:146-154: a nested torch.autograd.grad on a freshly flagged leaf -- LogisticRegression): capture refuses it."""
+    fns = list(score_fns)
+    inner = getattr(ctrl, "score", ctrl)  # RemoveReferenceCtrl wraps the score control
+    if hasattr(inner, "target_score"):
+        fns.append(inner.target_score)
+    return all(type(getattr(f, "__self__", None)).__name__ not in E._GRAPHLESS_SCORE for f in fns)
+
+
+def _graphed_step(loss, key, step, grads, example):
+    """``step`` captured as a hipGraph with static inputs / outputs (torch.cuda.graphs), cached on the loss per key; None if capture is not
+    possible (the caller then runs the step eagerly)."""
+    cache = loss.__dict__.setdefault("_step_graphs", {})
+    hit = cache.get(key)
+    if hit is None:
+        try:
+            hit = _GraphedAdjointStep(step, grads, example)
+        except Exception as e:  # noqa: BLE001 -- capture is an optimisation: run the steps eagerly, say so once
+            import warnings
+            warnings.warn(f"KL training: graph capture of the adjoint step failed ({type(e).__name__}: {e}); running it eagerly")
+            hit = False
+        cache[key] = hit
+    if hit is False:
+        return None
+    hit.reset()
+    return hit
+
+
+class _GraphedAdjointStep:
+    """One adjoint step (forward of the step's formulas + torch.autograd.grad) captured as a hipGraph.  The step function closes over
+    per-call tensors (the accumulators); the captured graph keeps its own static accumulators and inputs, refreshed per call."""
+
+    def __init__(self, step, grads, example):
+        self.static_in = [t.detach().clone() for t in example]
+        self.grads = [torch.zeros_like(g) for g in grads]
+        grads_backup = [g.clone() for g in grads]
+        self._swap(grads, self.grads)  # the closure accumulates into `grads`: make those our static buffers during warm-up / capture
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step(*self.static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = step(*self.static_in)
+        finally:  # whatever happened, the caller's accumulators get their own storage and their values back
+            torch.cuda.synchronize()
+            self._unswap(grads, grads_backup)
+
+    def _swap(self, grads, mine):
+        self._held = [g.data for g in grads]
+        for g, m in zip(grads, mine):
+            g.data = m.data
+
+    def _unswap(self, grads, backup):
+        for g, h, b in zip(grads, self._held, backup):
+            g.data = h
+            g.copy_(b)
+
+    def reset(self):
+        for g in self.grads:
+            g.zero_()
+
+    def __call__(self, *inputs):
+        for s, i in zip(self.static_in, inputs):
+            s.copy_(i)
+        self.graph.replay()
+        return self.static_out
 
 
 class DiscreteTimeReversalLossEI(_InitialLogProbLoss):
