@@ -24,4 +24,8 @@ def test_bench_under_torch_distributed_run(gpu):
                 "roofline", "log_z_abs_err"):
         assert key in j, key
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "weak" and j["value"] > 1e8
-    assert j["roofline"]["bound"] == "mfma" and j["log_z_abs_err"] < 1e-3
+    # the headline bound is the measured vector-port share when profiles/ holds counters of THIS library build (digest match), else the live
+    # matrix-pipe utilisation; either way a fraction in (0, 1]
+    assert j["roofline"]["bound"] in ("valu_issue", "mfma") and 0.0 < j["roofline"]["frac"] <= 1.0 and j["log_z_abs_err"] < 1e-3
+    if j["roofline"]["bound"] == "valu_issue":
+        assert j["roofline"]["traffic"] is not None and "library_digest" in j
