@@ -894,11 +894,16 @@ def _capturable(ctrl, *score_fns) -> bool:
 def _graphed_step(loss, key, step, grads, example):
     """``step`` captured as a hipGraph with static inputs / outputs (torch.cuda.graphs), cached on the loss per key; None if capture is not
     possible (the caller then runs the step eagerly)."""
+    import weakref
     cache = loss.__dict__.setdefault("_step_graphs", {})
+    ctrl_now = loss.generative_ctrl
     hit = cache.get(key)
+    if hit is not None and hit is not False and hit.owner() is not ctrl_now:
+        hit = None  # (another control object at a recycled id: the captured graph reads the old one's parameters)
     if hit is None:
         try:
             hit = _GraphedAdjointStep(step, grads, example)
+            hit.owner = weakref.ref(ctrl_now)
         except Exception as e:  # noqa: BLE001 -- capture is an optimisation: run the steps eagerly, say so once
             import warnings
             warnings.warn(f"KL training: graph capture of the adjoint step failed ({type(e).__name__}: {e}); running it eagerly")
