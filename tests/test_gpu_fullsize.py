@@ -230,7 +230,10 @@ def test_three_wave_kernels_at_full_occupancy(gpu, kind, d):
 # waves per SIMD (sim_kernel.hpp sd_waves_of: the phi^4 and no-reference families, small-d references) have 12 wave slots.
 BIG = [("rds_ei_gmm_d128_k16", 32768), ("rds_ei_gmm_d8_k4", 65536), ("rds_ddpm_gmm_d16_snr", 65536), ("rds_em_gmm_d16", 65536),
        ("rds_ei_vp_default_d16", 65536), ("rds_ei_pbm_default_d16", 65536), ("dds_two_modes_d2", 65536), ("dds_rings_d2", 65536),
-       ("dis_ei_d8", 65536), ("dis_orig_lerp_d8", 65536), ("pis_em_phi4_d100", 65536), ("cmcd_logreg_d61", 32768), ("cmcd_gmm_iso_d16", 65536), ("cmcd_gmm_diag_d40", 32768), ("cmcd_phi4_d100", 32768), ("pis_logreg_d61", 32768), ("dds_logreg_d61", 32768)]
+       ("dis_ei_d8", 65536), ("dis_orig_lerp_d8", 65536), ("pis_em_phi4_d100", 65536), ("cmcd_logreg_d61", 32768), ("cmcd_gmm_iso_d16", 65536), ("cmcd_gmm_diag_d40", 32768), ("cmcd_phi4_d100", 32768), ("pis_logreg_d61", 32768), ("dds_logreg_d61", 32768),
+       # full-covariance mixtures: as the reference (staged precision images, workgroup barriers per piece) and as the target of a score control
+       ("rds_ei_gmm_fullcov_d128_k4", 32768), ("rds_em_gmm_fullcov_d40_k3", 32768), ("pis_gmm_full_d128_k3", 32768), ("pis_two_modes_full_d20", 65536),
+       ("dds_two_modes_full_d5", 65536)]
 
 
 @pytest.mark.gpu
