@@ -221,6 +221,8 @@ def test_native_kl_adjoint_matches_autograd(gpu, d, K, lin, ito, N, B, clip, sco
     elif K > 1:
         ref = ("gmm", dict(means_init=1.5 * torch.randn(K, d, device=gpu), variances_init=0.4 + torch.rand(K, d, device=gpu), weights_init=0.5 + torch.rand(K, device=gpu)))
     arrays, lam0 = E.kl_adjoint(ctrl, coef, xs, z, w, lam_n, lin=lin, ito=ito, ref=ref)
+    arrays2, lam0_again = E.kl_adjoint(ctrl, coef, xs, z, w, lam_n, lin=lin, ito=ito, ref=ref)
+    assert torch.equal(lam0, lam0_again) and torch.equal(arrays["d0"], arrays2["d0"]) and torch.equal(arrays["dout"], arrays2["dout"]), "rerun differs"
     found = vjp_param_grads(ctrl, coef[:, 0].contiguous(), arrays, N, B)
     if score is not None:
         sm_params = list(ctrl.score_model.parameters())
